@@ -1,0 +1,110 @@
+"""ctypes binding of libfacehip.so (the C ABI in include/facehip.h).
+
+The library is the product; there is no CPU fallback.  If it is missing it is built with
+`make` (hipcc cross-compiles gfx950 without a GPU); if that fails the import fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfacehip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+FACE_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"),
+                       ("score", "<f4"), ("lm", "<f4", (10,))])
+assert FACE_DTYPE.itemsize == 60
+
+
+class FhFace(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
+                ("score", C.c_float), ("lm", C.c_float * 10)]
+
+
+def build(force: bool = False) -> str:
+    """Compile libfacehip.so in-tree (so that it travels with the source snapshot)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "facehip.h")]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-j8", "-s"])
+    return LIB_PATH
+
+
+_vp, _i, _f, _ll, _d = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_double
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); one row per symbol declared in include/facehip.h
+PROTOTYPES = {
+    "fh_version": (C.c_char_p, []),
+    "fh_last_error": (C.c_char_p, []),
+    "fh_init": (_i, [_i]),
+    "fh_plan_describe": (_i, [C.c_char_p, _i, _i, C.c_char_p, _i]),
+    "fh_det_create": (_vp, [C.c_char_p]),
+    "fh_det_destroy": (None, [_vp]),
+    "fh_det_input_size": (_i, [_vp, _ip, _ip]),
+    "fh_det_num_anchors": (_i, [_vp]),
+    "fh_det_macs_per_frame": (_d, [_vp]),
+    "fh_det_act_bytes_per_frame": (_d, [_vp]),
+    "fh_det_detect": (_i, [_vp, _vp, _i, _i, _i, _f, _f, _vp, _i]),
+    "fh_det_detect_batch_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _ll, _f, _f, _vp, _i, _vp, _vp]),
+    "fh_det_run_network_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _ll, _vp]),
+    "fh_det_num_outputs": (_i, [_vp]),
+    "fh_det_output_dev": (_vp, [_vp, _i, _ip, _ip]),
+    "fh_det_input_dev": (_vp, [_vp]),
+    "fh_det_postprocess_dev": (_i, [_vp, _i, _f, _f, _vp, _i, _vp, _vp]),
+    "fh_rec_create": (_vp, [C.c_char_p]),
+    "fh_rec_destroy": (None, [_vp]),
+    "fh_rec_input_size": (_i, [_vp, _ip, _ip]),
+    "fh_rec_feature_dim": (_i, [_vp]),
+    "fh_rec_macs_per_face": (_d, [_vp]),
+    "fh_rec_act_bytes_per_face": (_d, [_vp]),
+    "fh_rec_set_chunk": (_i, [_vp, _i]),
+    "fh_rec_extract": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i]),
+    "fh_rec_extract_simple": (_i, [_vp, _vp, _i, _i, _i, _vp, _i]),
+    "fh_compare": (_f, [_vp, _i, _vp, _i]),
+    "fh_rec_embed_aligned_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "fh_rec_align_dev": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _i, _vp, _vp, _vp]),
+    "fh_rec_embed_faces_dev": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _i, _vp, _vp, _vp]),
+    "fh_pipeline_run_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "fh_gallery_create": (_vp, [_i]),
+    "fh_gallery_destroy": (None, [_vp]),
+    "fh_gallery_upload": (_i, [_vp, _vp, _ll, _i, _ll]),
+    "fh_gallery_topk_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "fh_resize_u8c3_dev": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "fh_conv_forward_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "fh_conv_wt_rows": (_i, [_i]),
+    "fh_conv_kpad": (_i, [_i]),
+}
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        path = build()
+        L = C.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def last_error() -> str:
+    return lib().fh_last_error().decode(errors="replace")
+
+
+class FaceHipError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> int:
+    if rc < 0:
+        raise FaceHipError(f"{what} failed ({rc}): {last_error()}")
+    return rc

@@ -1,0 +1,217 @@
+"""Host-side mirror of the reference's class API over the C ABI (libfacehip.so).
+
+`FaceDetector` / `FaceRecognizer` keep the reference's method names, argument order, defaults and
+error behaviour (reference src/face_detector.h:14-43, src/face_recognizer.h:9-38):
+``loadModel`` returns False on failure, ``detect`` / ``extractFeature`` return empty results
+instead of raising, ``compareFaces`` returns 0.0 on size mismatch.  Images are numpy
+``uint8[rows, cols, 3]`` BGR arrays (the cv::Mat the reference takes).
+
+The ``*_dev`` methods are the batch additions: they take device pointers (e.g.
+``torch.Tensor.data_ptr()``) so frames stay resident in HBM between detect and embed.
+There is no CPU path here: without libfacehip.so and a GPU these classes fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import FACE_DTYPE, check
+
+
+@dataclass
+class FaceBox:
+    """struct FaceBox (src/face_detector.h:8-12): box = (x, y, width, height)."""
+    box: tuple = (0, 0, 0, 0)
+    score: float = 0.0
+    landmarks: np.ndarray = field(default_factory=lambda: np.zeros((5, 2), np.float32))
+
+    def to_record(self) -> np.ndarray:
+        r = np.zeros(1, FACE_DTYPE)
+        r[0]["x"], r[0]["y"], r[0]["w"], r[0]["h"] = self.box
+        r[0]["score"] = self.score
+        r[0]["lm"] = np.asarray(self.landmarks, np.float32).reshape(10)
+        return r
+
+    @staticmethod
+    def from_record(r) -> "FaceBox":
+        return FaceBox((int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])), float(r["score"]),
+                       np.array(r["lm"], np.float32).reshape(5, 2))
+
+
+def _img(image) -> Optional[np.ndarray]:
+    if image is None:
+        return None
+    a = np.asarray(image)
+    if a.size == 0:
+        return None
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise TypeError("image must be uint8[rows, cols, 3] (BGR)")
+    if a.strides[2] != 1 or a.strides[1] != 3:
+        a = np.ascontiguousarray(a)
+    return a
+
+
+class FaceDetector:
+    def __init__(self):
+        self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().fh_det_destroy(self._h)
+            self._h = None
+
+    # -- reference API ---------------------------------------------------------------------
+    def loadModel(self, modelPath: str) -> bool:                      # face_detector.cpp:20-90
+        self.close()
+        self._h = _lib.lib().fh_det_create(str(modelPath).encode())
+        return bool(self._h)
+
+    def detect_records(self, image, scoreThreshold: float = 0.5, nmsThreshold: float = 0.4,
+                       max_faces: int = 4096) -> np.ndarray:
+        if not self._h:
+            return np.zeros(0, FACE_DTYPE)                            # "Model not loaded!" :142-145
+        a = _img(image)
+        if a is None:
+            return np.zeros(0, FACE_DTYPE)                            # :148-156
+        out = np.zeros(max_faces, FACE_DTYPE)
+        n = check(_lib.lib().fh_det_detect(self._h, a.ctypes.data, a.shape[0], a.shape[1], a.strides[0],
+                                            scoreThreshold, nmsThreshold, out.ctypes.data, max_faces), "fh_det_detect")
+        return out[:n].copy()
+
+    def detect(self, image, scoreThreshold: float = 0.5, nmsThreshold: float = 0.4) -> List[FaceBox]:
+        return [FaceBox.from_record(r) for r in self.detect_records(image, scoreThreshold, nmsThreshold)]
+
+    # -- batch / device additions -----------------------------------------------------------
+    @property
+    def handle(self):
+        return self._h
+
+    def input_size(self):
+        w, h = C.c_int(), C.c_int()
+        check(_lib.lib().fh_det_input_size(self._h, C.byref(w), C.byref(h)), "fh_det_input_size")
+        return w.value, h.value
+
+    def num_anchors(self) -> int:
+        return _lib.lib().fh_det_num_anchors(self._h)
+
+    def macs_per_frame(self) -> float:
+        return _lib.lib().fh_det_macs_per_frame(self._h)
+
+    def detect_batch_dev(self, frames_ptr: int, n: int, rows: int, cols: int, out_ptr: int, max_per_frame: int,
+                         counts_ptr: int, scoreThreshold: float = 0.5, nmsThreshold: float = 0.4,
+                         step: int = 0, frame_stride: int = 0, stream: int = 0) -> int:
+        step = step or cols * 3
+        frame_stride = frame_stride or rows * step
+        return check(_lib.lib().fh_det_detect_batch_dev(self._h, frames_ptr, n, rows, cols, step, frame_stride,
+                                                        scoreThreshold, nmsThreshold, out_ptr, max_per_frame,
+                                                        counts_ptr, stream), "fh_det_detect_batch_dev")
+
+
+class FaceRecognizer:
+    def __init__(self):
+        self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().fh_rec_destroy(self._h)
+            self._h = None
+
+    # -- reference API ---------------------------------------------------------------------
+    def loadModel(self, modelPath: str) -> bool:                      # face_recognizer.cpp:21-91
+        self.close()
+        self._h = _lib.lib().fh_rec_create(str(modelPath).encode())
+        return bool(self._h)
+
+    def extractFeature(self, image, face) -> np.ndarray:             # face_recognizer.cpp:236-304
+        if not self._h:
+            return np.zeros(0, np.float32)
+        a = _img(image)
+        if a is None:
+            return np.zeros(0, np.float32)
+        rec = face.to_record() if isinstance(face, FaceBox) else np.asarray(face, FACE_DTYPE).reshape(1)
+        dim = self.feature_dim()
+        out = np.zeros(dim, np.float32)
+        n = check(_lib.lib().fh_rec_extract(self._h, a.ctypes.data, a.shape[0], a.shape[1], a.strides[0],
+                                             rec.ctypes.data, out.ctypes.data, dim), "fh_rec_extract")
+        return out[:n]
+
+    def extractFeatureSimple(self, image) -> np.ndarray:             # face_recognizer.cpp:152-234
+        if not self._h:
+            return np.zeros(0, np.float32)
+        a = _img(image)
+        if a is None:
+            return np.zeros(0, np.float32)
+        dim = self.feature_dim()
+        out = np.zeros(dim, np.float32)
+        n = check(_lib.lib().fh_rec_extract_simple(self._h, a.ctypes.data, a.shape[0], a.shape[1], a.strides[0],
+                                                    out.ctypes.data, dim), "fh_rec_extract_simple")
+        return out[:n]
+
+    @staticmethod
+    def compareFaces(feature1, feature2) -> float:                   # face_recognizer.cpp:320-334
+        f1 = np.ascontiguousarray(feature1, np.float32).reshape(-1)
+        f2 = np.ascontiguousarray(feature2, np.float32).reshape(-1)
+        return float(_lib.lib().fh_compare(f1.ctypes.data, f1.size, f2.ctypes.data, f2.size))
+
+    # -- batch / device additions -----------------------------------------------------------
+    @property
+    def handle(self):
+        return self._h
+
+    def feature_dim(self) -> int:
+        return _lib.lib().fh_rec_feature_dim(self._h)
+
+    def macs_per_face(self) -> float:
+        return _lib.lib().fh_rec_macs_per_face(self._h)
+
+    def set_chunk(self, n: int):
+        check(_lib.lib().fh_rec_set_chunk(self._h, n), "fh_rec_set_chunk")
+
+    def embed_aligned_dev(self, crops_ptr: int, n: int, out_ptr: int, raw_ptr: int = 0, stream: int = 0) -> int:
+        return check(_lib.lib().fh_rec_embed_aligned_dev(self._h, crops_ptr, n, out_ptr, raw_ptr, stream),
+                     "fh_rec_embed_aligned_dev")
+
+
+def pipeline_run_dev(det: FaceDetector, rec: FaceRecognizer, frames_ptr: int, n: int, rows: int, cols: int,
+                     faces_per_frame: int, faces_ptr: int, frame_of_ptr: int, emb_ptr: int,
+                     scoreThreshold: float = 0.5, nmsThreshold: float = 0.4, stream: int = 0) -> int:
+    """detect -> align -> embed on n HBM-resident frames; returns the number of faces embedded."""
+    step = cols * 3
+    return check(_lib.lib().fh_pipeline_run_dev(det.handle, rec.handle, frames_ptr, n, rows, cols, step, rows * step,
+                                                scoreThreshold, nmsThreshold, faces_per_frame, faces_ptr,
+                                                frame_of_ptr, emb_ptr, stream), "fh_pipeline_run_dev")
+
+
+class Gallery:
+    """1:N generalisation of compareFaces: top-k mapped scores (dot+1)/2 over enrolled rows."""
+
+    def __init__(self, dim: int = 512):
+        self._h = _lib.lib().fh_gallery_create(dim)
+        self.dim = dim
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.lib().fh_gallery_destroy(self._h)
+            self._h = None
+
+    def upload(self, rows_ptr: int, n: int, on_device: bool, index_base: int = 0):
+        check(_lib.lib().fh_gallery_upload(self._h, rows_ptr, n, int(on_device), index_base), "fh_gallery_upload")
+
+    def topk_dev(self, q_ptr: int, nq: int, k: int, scores_ptr: int, idx_ptr: int, stream: int = 0):
+        check(_lib.lib().fh_gallery_topk_dev(self._h, q_ptr, nq, k, scores_ptr, idx_ptr, stream), "fh_gallery_topk_dev")
+
+
+def plan_describe(path: str, default_h: int, default_w: int) -> str:
+    buf = C.create_string_buffer(1 << 18)
+    check(_lib.lib().fh_plan_describe(str(path).encode(), default_h, default_w, buf, len(buf)), "fh_plan_describe")
+    return buf.value.decode()

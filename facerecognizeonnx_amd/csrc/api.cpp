@@ -1,0 +1,305 @@
+// api.cpp — the extern "C" boundary declared in include/facehip.h.
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "../../include/facehip.h"
+#include "engine.h"
+
+static_assert(sizeof(fh_face) == 60 && sizeof(fh::FaceRec) == 60, "FaceBox mirror must stay 60 bytes");
+
+namespace {
+thread_local std::string g_err;
+
+template <class F>
+int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        const bool dev = g_err.rfind("HIP error", 0) == 0;
+        return dev ? FH_ERR_DEVICE : (g_err.rfind("onnx", 0) == 0 || g_err.rfind("plan", 0) == 0) ? FH_ERR_MODEL : FH_ERR_STATE;
+    } catch (...) {
+        g_err = "unknown exception";
+        return FH_ERR_STATE;
+    }
+}
+int arg_error(const char* msg) { g_err = msg; return FH_ERR_ARG; }
+hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+}  // namespace
+
+struct fh_det {
+    explicit fh_det(const char* p) : det(p) {}
+    fh::Detector det;
+    fh::DevBuf img, out, cnt;            // staging for the host-pointer API
+    fh::DevBuf p_det, p_cnt, p_total;    // pipeline scratch
+};
+struct fh_rec {
+    explicit fh_rec(const char* p) : rec(p) {}
+    fh::Recognizer rec;
+    fh::DevBuf img, face, emb;
+};
+struct fh_gallery {
+    explicit fh_gallery(int dim) : g(dim) {}
+    fh::Gallery g;
+};
+
+extern "C" {
+
+const char* fh_version(void) { return "facehip 0.1 (gfx950)"; }
+const char* fh_last_error(void) { return g_err.c_str(); }
+
+int fh_init(int device) {
+    return guarded([&] {
+        int n = 0;
+        FH_HIP(hipGetDeviceCount(&n));
+        if (device < 0 || device >= n) throw std::runtime_error("HIP error: no such device");
+        FH_HIP(hipSetDevice(device));
+        return n;
+    });
+}
+
+int fh_plan_describe(const char* onnx_path, int default_h, int default_w, char* buf, int cap) {
+    if (!onnx_path || !buf || cap <= 0) return arg_error("fh_plan_describe: null argument");
+    return guarded([&] {
+        fh::OnnxModel m = fh::load_onnx(onnx_path);
+        int H = default_h, W = default_w;
+        const auto& shp = m.inputs[0].shape;
+        if (shp.size() == 4) { if (shp[2] > 0) H = (int)shp[2]; if (shp[3] > 0) W = (int)shp[3]; }
+        fh::Plan p = fh::build_plan(m, H, W);
+        std::string s = p.describe();
+        snprintf(buf, (size_t)cap, "%s", s.c_str());
+        return (int)s.size();
+    });
+}
+
+// ---------------------------------------------------------------------------------- detector
+fh_det* fh_det_create(const char* onnx_path) {
+    if (!onnx_path) { g_err = "fh_det_create: null path"; return nullptr; }
+    fh_det* h = nullptr;
+    int rc = guarded([&] { h = new fh_det(onnx_path); return 0; });
+    return rc == 0 ? h : nullptr;
+}
+void fh_det_destroy(fh_det* d) { delete d; }
+int fh_det_input_size(const fh_det* d, int* w, int* h) {
+    if (!d) return arg_error("null handle");
+    if (w) *w = const_cast<fh_det*>(d)->det.net().in_w();
+    if (h) *h = const_cast<fh_det*>(d)->det.net().in_h();
+    return FH_OK;
+}
+int fh_det_num_anchors(const fh_det* d) { return d ? d->det.num_anchors() : arg_error("null handle"); }
+double fh_det_macs_per_frame(const fh_det* d) { return d ? const_cast<fh_det*>(d)->det.net().plan().macs : 0.0; }
+double fh_det_act_bytes_per_frame(const fh_det* d) { return d ? const_cast<fh_det*>(d)->det.net().plan().act_bytes : 0.0; }
+
+int fh_det_detect_batch_dev(fh_det* d, const uint8_t* frames, int n, int rows, int cols, int step, long long stride,
+                            float score_thr, float nms_thr, fh_face* out, int max_pf, int* counts, void* stream) {
+    if (!d || !frames || !out || !counts) return arg_error("fh_det_detect_batch_dev: null argument");
+    if (n <= 0 || rows <= 0 || cols <= 0 || step < cols * 3 || max_pf <= 0) return arg_error("fh_det_detect_batch_dev: bad size");
+    return guarded([&] {
+        d->det.detect_dev(frames, n, rows, cols, step, (long)stride, score_thr, nms_thr, reinterpret_cast<fh::FaceRec*>(out), max_pf,
+                          counts, S(stream));
+        return n;
+    });
+}
+
+int fh_det_detect(fh_det* d, const uint8_t* bgr, int rows, int cols, int step, float score_thr, float nms_thr, fh_face* out,
+                  int max_out) {
+    if (!d) return arg_error("Model not loaded!");                       // src/face_detector.cpp:142-145
+    if (!bgr || rows <= 0 || cols <= 0) return 0;                        // :148-156 -> empty result
+    if (!out || max_out <= 0 || step < cols * 3) return arg_error("fh_det_detect: bad output buffer / step");
+    return guarded([&] {
+        const size_t bytes = (size_t)rows * step;
+        d->img.ensure(bytes);
+        d->out.ensure((size_t)max_out * sizeof(fh_face));
+        d->cnt.ensure(sizeof(int));
+        FH_HIP(hipMemcpy(d->img.p, bgr, bytes, hipMemcpyHostToDevice));
+        try {
+            d->det.detect_dev(d->img.as<uint8_t>(), 1, rows, cols, step, (long)bytes, score_thr, nms_thr, d->out.as<fh::FaceRec>(),
+                              max_out, d->cnt.as<int>(), nullptr);
+        } catch (const std::runtime_error& e) {
+            if (std::string(e.what()) == "Invalid resize dimensions") return 0;   // :109-113,164-167
+            throw;
+        }
+        int c = 0;
+        FH_HIP(hipMemcpy(&c, d->cnt.p, sizeof(int), hipMemcpyDeviceToHost));
+        c = c < max_out ? c : max_out;
+        if (c > 0) FH_HIP(hipMemcpy(out, d->out.p, (size_t)c * sizeof(fh_face), hipMemcpyDeviceToHost));
+        return c;
+    });
+}
+
+int fh_det_run_network_dev(fh_det* d, const uint8_t* frames, int n, int rows, int cols, int step, long long stride, void* stream) {
+    if (!d || !frames || n <= 0) return arg_error("fh_det_run_network_dev: bad argument");
+    return guarded([&] { d->det.run_network_dev(frames, n, rows, cols, step, (long)stride, S(stream)); return n; });
+}
+int fh_det_num_outputs(const fh_det* d) { return d ? (int)const_cast<fh_det*>(d)->det.net().plan().outputs.size() : arg_error("null handle"); }
+const float* fh_det_output_dev(fh_det* d, int index, int* rows, int* cols) {
+    if (!d || index < 0 || index >= (int)d->det.net().plan().outputs.size()) { g_err = "bad output index"; return nullptr; }
+    const auto& o = d->det.net().plan().outputs[index];
+    if (rows) *rows = o.rows;
+    if (cols) *cols = o.cols;
+    return d->det.net().capacity() > 0 ? d->det.net().output(index) : nullptr;
+}
+const float* fh_det_input_dev(fh_det* d) { return d && d->det.net().capacity() > 0 ? d->det.net().input() : nullptr; }
+int fh_det_postprocess_dev(fh_det* d, int n, float score_thr, float nms_thr, fh_face* out, int max_pf, int* counts, void* stream) {
+    if (!d || !out || !counts || n <= 0) return arg_error("fh_det_postprocess_dev: bad argument");
+    return guarded([&] { d->det.postprocess_dev(n, score_thr, nms_thr, reinterpret_cast<fh::FaceRec*>(out), max_pf, counts, S(stream)); return n; });
+}
+
+// ---------------------------------------------------------------------------------- recognizer
+fh_rec* fh_rec_create(const char* onnx_path) {
+    if (!onnx_path) { g_err = "fh_rec_create: null path"; return nullptr; }
+    fh_rec* h = nullptr;
+    int rc = guarded([&] { h = new fh_rec(onnx_path); return 0; });
+    return rc == 0 ? h : nullptr;
+}
+void fh_rec_destroy(fh_rec* r) { delete r; }
+int fh_rec_input_size(const fh_rec* r, int* w, int* h) {
+    if (!r) return arg_error("null handle");
+    if (w) *w = const_cast<fh_rec*>(r)->rec.net().in_w();
+    if (h) *h = const_cast<fh_rec*>(r)->rec.net().in_h();
+    return FH_OK;
+}
+int fh_rec_feature_dim(const fh_rec* r) { return r ? r->rec.dim() : arg_error("null handle"); }
+double fh_rec_macs_per_face(const fh_rec* r) { return r ? const_cast<fh_rec*>(r)->rec.net().plan().macs : 0.0; }
+double fh_rec_act_bytes_per_face(const fh_rec* r) { return r ? const_cast<fh_rec*>(r)->rec.net().plan().act_bytes : 0.0; }
+int fh_rec_set_chunk(fh_rec* r, int n) {
+    if (!r || n <= 0) return arg_error("fh_rec_set_chunk: bad argument");
+    r->rec.max_chunk = n;
+    return FH_OK;
+}
+
+int fh_rec_embed_aligned_dev(fh_rec* r, const uint8_t* crops, int n, float* out, float* raw, void* stream) {
+    if (!r || !crops || !out || n <= 0) return arg_error("fh_rec_embed_aligned_dev: bad argument");
+    return guarded([&] { r->rec.embed_aligned_dev(crops, n, out, S(stream), raw); return n; });
+}
+int fh_rec_align_dev(fh_rec* r, const uint8_t* frames, int rows, int cols, int step, long long stride, const fh_face* faces,
+                     const int* frame_of, int n, uint8_t* crops, int* ok, void* stream) {
+    if (!r || !frames || !faces || !crops || !ok || n <= 0 || rows <= 0 || cols <= 0) return arg_error("fh_rec_align_dev: bad argument");
+    return guarded([&] {
+        r->rec.align_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, n, crops, ok, S(stream));
+        return n;
+    });
+}
+int fh_rec_embed_faces_dev(fh_rec* r, const uint8_t* frames, int rows, int cols, int step, long long stride, const fh_face* faces,
+                           const int* frame_of, int n, float* out, int* ok, void* stream) {
+    if (!r || !frames || !faces || !out || n <= 0 || rows <= 0 || cols <= 0) return arg_error("fh_rec_embed_faces_dev: bad argument");
+    return guarded([&] {
+        r->rec.embed_faces_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, n, out, ok, S(stream));
+        return n;
+    });
+}
+
+int fh_rec_extract(fh_rec* r, const uint8_t* bgr, int rows, int cols, int step, const fh_face* face, float* out, int out_cap) {
+    if (!r) return arg_error("Model not loaded!");                        // src/face_recognizer.cpp:239-242
+    if (!bgr || rows <= 0 || cols <= 0) return 0;                         // :245-248 -> empty vector
+    if (!face || !out || step < cols * 3) return arg_error("fh_rec_extract: bad argument");
+    if (out_cap < r->rec.dim()) return arg_error("fh_rec_extract: output buffer too small");
+    return guarded([&] {
+        const size_t bytes = (size_t)rows * step;
+        r->img.ensure(bytes);
+        r->face.ensure(sizeof(fh_face) + sizeof(int));
+        r->emb.ensure((size_t)r->rec.dim() * sizeof(float));
+        FH_HIP(hipMemcpy(r->img.p, bgr, bytes, hipMemcpyHostToDevice));
+        FH_HIP(hipMemcpy(r->face.p, face, sizeof(fh_face), hipMemcpyHostToDevice));
+        int* okp = reinterpret_cast<int*>(r->face.as<uint8_t>() + sizeof(fh_face));
+        r->rec.embed_faces_dev(r->img.as<uint8_t>(), rows, cols, step, (long)bytes, r->face.as<fh::FaceRec>(), nullptr, 1, r->emb.as<float>(), okp, nullptr);
+        int ok = 0;
+        FH_HIP(hipMemcpy(&ok, okp, sizeof(int), hipMemcpyDeviceToHost));
+        if (!ok) return 0;                                                 // "Face alignment failed!" :254-257
+        FH_HIP(hipMemcpy(out, r->emb.p, (size_t)r->rec.dim() * sizeof(float), hipMemcpyDeviceToHost));
+        return r->rec.dim();
+    });
+}
+
+int fh_rec_extract_simple(fh_rec* r, const uint8_t* bgr, int rows, int cols, int step, float* out, int out_cap) {
+    if (!r) return arg_error("Model not loaded!");
+    if (!bgr || rows <= 0 || cols <= 0) return 0;
+    if (!out || step < cols * 3) return arg_error("fh_rec_extract_simple: bad argument");
+    if (out_cap < r->rec.dim()) return arg_error("fh_rec_extract_simple: output buffer too small");
+    return guarded([&] {
+        const size_t bytes = (size_t)rows * step;
+        r->img.ensure(bytes);
+        r->emb.ensure((size_t)r->rec.dim() * sizeof(float));
+        FH_HIP(hipMemcpy(r->img.p, bgr, bytes, hipMemcpyHostToDevice));
+        r->rec.resize_embed_dev(r->img.as<uint8_t>(), 1, rows, cols, step, (long)bytes, r->emb.as<float>(), nullptr);
+        FH_HIP(hipMemcpy(out, r->emb.p, (size_t)r->rec.dim() * sizeof(float), hipMemcpyDeviceToHost));
+        return r->rec.dim();
+    });
+}
+
+// FaceRecognizer::compareFaces (src/face_recognizer.cpp:320-334) — 1 024 FLOP, stays on the host.
+float fh_compare(const float* f1, int n1, const float* f2, int n2) {
+    if (n1 != n2 || n1 <= 0 || !f1 || !f2) return 0.0f;
+    float dot = 0.0f;
+    for (int i = 0; i < n1; ++i) dot += f1[i] * f2[i];
+    return (dot + 1.0f) / 2.0f;
+}
+
+// ---------------------------------------------------------------------------------- pipeline
+int fh_pipeline_run_dev(fh_det* d, fh_rec* r, const uint8_t* frames, int n, int rows, int cols, int step, long long stride,
+                        float score_thr, float nms_thr, int F, fh_face* faces, int* frame_of, float* emb, void* stream) {
+    if (!d || !r || !frames || !faces || !frame_of || !emb) return arg_error("fh_pipeline_run_dev: null argument");
+    if (n <= 0 || n > 4096 || rows <= 0 || cols <= 0 || F <= 0) return arg_error("fh_pipeline_run_dev: bad size");
+    return guarded([&] {
+        hipStream_t s = S(stream);
+        d->p_det.ensure((size_t)n * F * sizeof(fh_face));
+        d->p_cnt.ensure((size_t)n * sizeof(int));
+        d->p_total.ensure(sizeof(int));
+        d->det.detect_dev(frames, n, rows, cols, step, (long)stride, score_thr, nms_thr, d->p_det.as<fh::FaceRec>(), F, d->p_cnt.as<int>(), s);
+        fh::launch_select_faces(d->p_det.as<fh::FaceRec>(), d->p_cnt.as<int>(), n, F, F, reinterpret_cast<fh::FaceRec*>(faces), frame_of,
+                                d->p_total.as<int>(), s);
+        int total = 0;
+        FH_HIP(hipMemcpyAsync(&total, d->p_total.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        FH_HIP(hipStreamSynchronize(s));
+        if (total > 0)
+            r->rec.embed_faces_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, total, emb,
+                                   nullptr, s);
+        return total;
+    });
+}
+
+// ---------------------------------------------------------------------------------- gallery
+fh_gallery* fh_gallery_create(int dim) {
+    if (dim <= 0) { g_err = "fh_gallery_create: bad dim"; return nullptr; }
+    return new fh_gallery(dim);
+}
+void fh_gallery_destroy(fh_gallery* g) { delete g; }
+int fh_gallery_upload(fh_gallery* g, const float* rows, long long n, int on_device, long long index_base) {
+    if (!g || !rows || n <= 0) return arg_error("fh_gallery_upload: bad argument");
+    return guarded([&] { g->g.upload(rows, (long)n, on_device != 0, (long)index_base); return 0; });
+}
+int fh_gallery_topk_dev(fh_gallery* g, const float* q, int nq, int k, float* scores, int* indices, void* stream) {
+    if (!g || !q || !scores || !indices) return arg_error("fh_gallery_topk_dev: null argument");
+    return guarded([&] { g->g.topk_dev(q, nq, k, scores, indices, S(stream)); return nq; });
+}
+
+// ---------------------------------------------------------------------------------- single kernels
+int fh_resize_u8c3_dev(const uint8_t* src, int sh, int sw, int sstep, uint8_t* dst, int dh, int dw, int dstep, void* stream) {
+    if (!src || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0) return arg_error("fh_resize_u8c3_dev: bad argument");
+    return guarded([&] {
+        fh::launch_resize_u8c3(src, (long)sh * sstep, sh, sw, sstep, dst, (long)dh * dstep, dh, dw, dstep, 1, S(stream));
+        FH_HIP(hipGetLastError());
+        return 0;
+    });
+}
+int fh_conv_wt_rows(int cout) { return fh::conv_wt_rows(cout); }
+int fh_conv_kpad(int ktot) { return fh::conv_kpad(ktot); }
+int fh_conv_forward_dev(const float* in, const float* wt, const float* bias, float* out, int batch, int h, int w, int cin, int cout,
+                        int ks, int stride, int kpad, int cfg, void* stream) {
+    if (!in || !wt || !out || batch <= 0 || (ks != 1 && ks != 3) || cin % 4) return arg_error("fh_conv_forward_dev: bad argument");
+    return guarded([&] {
+        fh::ConvArgs a{};
+        const int pad = ks / 2;
+        a.in = in; a.wt = wt; a.bias = bias; a.out1 = out;
+        a.B = batch; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.ks = ks; a.stride = stride; a.pad = pad;
+        a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1;
+        a.Kpad = kpad; a.nsplit = 1;
+        fh::launch_conv(a, cfg, S(stream));
+        FH_HIP(hipGetLastError());
+        return 0;
+    });
+}
+
+}  // extern "C"

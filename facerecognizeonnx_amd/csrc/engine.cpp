@@ -1,0 +1,306 @@
+// engine.cpp — weight upload, arena management and the launch sequences of the face path.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace fh {
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " in " + what);
+}
+
+DevBuf::~DevBuf() {
+    if (p) (void)hipFree(p);
+}
+void DevBuf::ensure(size_t n) {
+    if (n <= bytes) return;
+    if (p) { FH_HIP(hipDeviceSynchronize()); FH_HIP(hipFree(p)); p = nullptr; bytes = 0; }
+    FH_HIP(hipMalloc(&p, n));
+    bytes = n;
+}
+
+// ------------------------------------------------------------------------------------------ Net
+static constexpr size_t kPartialFloats = (size_t)2 * 512 * 128 * 128;
+
+Net::Net(const std::string& onnx_path, int default_h, int default_w) {
+    OnnxModel m = load_onnx(onnx_path);
+    // reference src/face_detector.cpp:39-57: adopt the model's static H/W when > 0, else keep defaults
+    int H = default_h, W = default_w;
+    const auto& shp = m.inputs[0].shape;
+    if (shp.size() == 4) {
+        if (shp[2] > 0) H = (int)shp[2];
+        if (shp[3] > 0) W = (int)shp[3];
+    }
+    plan_ = build_plan(m, H, W);
+
+    std::vector<float> host;
+    auto push = [&](const float* src, size_t n) {
+        size_t off = (host.size() + 63) / 64 * 64;
+        host.resize(off + n, 0.f);
+        if (n) memcpy(host.data() + off, src, n * sizeof(float));
+        return off;
+    };
+    dev_.resize(plan_.ops.size());
+    for (size_t i = 0; i < plan_.ops.size(); ++i) {
+        const POp& op = plan_.ops[i];
+        DevOp& d = dev_[i];
+        if (op.kind == OpKind::CONV || op.kind == OpKind::GEMM) {
+            const int Ktot = op.ks * op.ks * op.Cin;
+            d.Kpad = conv_kpad(Ktot);
+            const int rows = conv_wt_rows(op.Cout);
+            std::vector<float> packed((size_t)rows * d.Kpad, 0.f);
+            for (int co = 0; co < op.Cout; ++co) memcpy(&packed[(size_t)co * d.Kpad], &op.weight[(size_t)co * Ktot], (size_t)Ktot * 4);
+            d.wt = push(packed.data(), packed.size());
+        } else if (op.kind == OpKind::DWCONV) {
+            d.wt = push(op.weight.data(), op.weight.size());
+        }
+        if (!op.bias.empty()) d.bias = push(op.bias.data(), op.bias.size());
+        if (!op.slope.empty()) { d.slope = push(op.slope.data(), op.slope.size()); d.has_slope = true; }
+        if (!op.s2.empty()) { d.s2 = push(op.s2.data(), op.s2.size()); d.t2 = push(op.t2.data(), op.t2.size()); d.has_aff = true; }
+    }
+    params_.ensure(std::max<size_t>(host.size(), 64) * sizeof(float));
+    FH_HIP(hipMemcpy(params_.p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    // host copies of the weights are no longer needed
+    for (auto& op : plan_.ops) { std::vector<float>().swap(op.weight); }
+}
+
+void Net::reserve(int max_batch) {
+    if (max_batch <= cap_) return;
+    cap_ = max_batch;
+    arena_.ensure(plan_.arena_elems * (size_t)cap_ * sizeof(float));
+    partial_.ensure(kPartialFloats * sizeof(float));
+    // the 4th input lane and alignment gaps must never hold NaNs
+    FH_HIP(hipMemset(arena_.p, 0, arena_.bytes));
+}
+
+int Net::pick_split(const POp& op, int batch, int cfg) const {
+    static const int bm[4] = {128, 256, 128, 64}, bn[4] = {128, 64, 32, 64};
+    const long M = (long)batch * op.Ho * op.Wo;
+    const long tiles = ((M + bm[cfg] - 1) / bm[cfg]) * ((op.Cout + bn[cfg] - 1) / bn[cfg]);
+    const int chunks = conv_kpad(op.ks * op.ks * op.Cin) / 32;
+    if (tiles >= 256 || chunks < 16) return 1;
+    long ns = std::min<long>((512 + tiles - 1) / tiles, chunks / 8);
+    while (ns > 1 && (size_t)ns * M * op.Cout > kPartialFloats) --ns;
+    return (int)std::max<long>(1, ns);
+}
+
+void Net::run(int batch, hipStream_t s) {
+    if (batch <= 0) return;
+    if (batch > cap_) throw std::runtime_error("Net::run: batch exceeds reserved capacity");
+    const float* P = params_.as<float>();
+    for (size_t i = 0; i < plan_.ops.size(); ++i) {
+        const POp& op = plan_.ops[i];
+        const DevOp& d = dev_[i];
+        switch (op.kind) {
+            case OpKind::CONV:
+            case OpKind::GEMM: {
+                ConvArgs a{};
+                a.in = tensor_ptr(op.in);
+                a.wt = P + d.wt;
+                a.bias = P + d.bias;
+                a.slope = d.has_slope ? P + d.slope : nullptr;
+                a.res = op.res >= 0 ? tensor_ptr(op.res) : nullptr;
+                a.out1 = op.out >= 0 ? tensor_ptr(op.out) : nullptr;
+                a.out2 = op.out2 >= 0 ? tensor_ptr(op.out2) : nullptr;
+                a.s2 = d.has_aff ? P + d.s2 : nullptr;
+                a.t2 = d.has_aff ? P + d.t2 : nullptr;
+                a.partial = partial_.as<float>();
+                a.B = batch; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
+                a.ks = op.ks; a.stride = op.stride; a.pad = op.pad; a.Kpad = d.Kpad;
+                a.act = (int)op.act; a.res_mode = (int)op.res_mode;
+                const long M = (long)batch * op.Ho * op.Wo;
+                int cfg = force_cfg >= 0 ? force_cfg : conv_pick_cfg(M, op.Cout);
+                if (force_cfg < 0 && cfg == 0 && ((M + 127) / 128) * ((op.Cout + 127) / 128) < 256) cfg = 3;   // few tiles: go finer
+                a.nsplit = pick_split(op, batch, cfg);
+                launch_conv(a, cfg, s);
+                break;
+            }
+            case OpKind::DWCONV:
+                launch_dwconv3x3(tensor_ptr(op.in), P + d.wt, P + d.bias, tensor_ptr(op.out), batch, op.H, op.W, op.Cin, op.stride,
+                                 (int)op.act, s);
+                break;
+            case OpKind::AFFINE:
+                launch_affine(tensor_ptr(op.in), P + d.s2, P + d.t2, tensor_ptr(op.out), (long)batch * op.H * op.W, op.Cin, s);
+                break;
+            case OpKind::ACT:
+                launch_act(tensor_ptr(op.in), d.has_slope ? P + d.slope : nullptr, tensor_ptr(op.out), (long)batch * op.H * op.W,
+                           op.Cin, (int)op.act, s);
+                break;
+            case OpKind::ADD:
+                launch_add(tensor_ptr(op.in), tensor_ptr(op.in2), tensor_ptr(op.out), (long)batch * op.H * op.W * op.Cin, s);
+                break;
+            case OpKind::UPSAMPLE:
+                launch_upsample2x(tensor_ptr(op.in), tensor_ptr(op.out), batch, op.H, op.W, op.Cin, s);
+                break;
+        }
+    }
+    FH_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------------------------------ Detector
+Detector::Detector(const std::string& onnx_path) : net_(onnx_path, 640, 640) {   // defaults: src/face_detector.cpp:8-9
+    const auto& outs = net_.plan().outputs;
+    const int H = net_.in_h(), W = net_.in_w();
+    if (outs.size() == 9) {
+        static const int cols[9] = {1, 1, 1, 4, 4, 4, 10, 10, 10};
+        static const int strides[3] = {8, 16, 32};
+        bool ok = true;
+        for (int i = 0; i < 9; ++i) {
+            const int s = strides[i % 3];
+            ok = ok && outs[i].cols == cols[i] && outs[i].rows == (H / s) * (W / s) * 2;
+        }
+        if (ok) anchors_ = ((H / 8) * (W / 8) + (H / 16) * (W / 16) + (H / 32) * (W / 32)) * 2;
+    } else if (outs.size() >= 1 && outs[0].cols >= 15) {
+        // the reference's own assumption: output 0 already is [*, N, >=15] (src/face_detector.cpp:242-325)
+        predecoded_ = true;
+        anchors_ = outs[0].rows;
+        feat_ = outs[0].cols;
+    }
+    // anything else: "Unexpected output shape format" -> zero faces (src/face_detector.cpp:326-328)
+    cap_ = 1;
+    while (cap_ < std::max(anchors_, 1)) cap_ <<= 1;
+}
+
+void Detector::reserve(int n, int rows, int cols) {
+    (void)rows; (void)cols;
+    net_.reserve(n);
+    if (n > nb_) {
+        nb_ = n;
+        cand_.ensure((size_t)n * cap_ * sizeof(FaceRec));
+        keys_.ensure((size_t)n * cap_ * sizeof(unsigned long long));
+        ws_.ensure((size_t)n * cap_ * sizeof(int));
+        count_.ensure((size_t)n * sizeof(int));
+    }
+}
+
+void Detector::run_network_dev(const uint8_t* frames, int n, int rows, int cols, int step, long stride, hipStream_t s) {
+    reserve(n, rows, cols);
+    const int inW = net_.in_w(), inH = net_.in_h();
+    // src/face_detector.cpp:101-106
+    const float scaleW = (float)inW / (float)cols, scaleH = (float)inH / (float)rows;
+    scale_ = std::min(scaleW, scaleH);
+    const int newW = (int)((float)cols * scale_), newH = (int)((float)rows * scale_);
+    if (newW <= 0 || newH <= 0) throw std::runtime_error("Invalid resize dimensions");   // :109-113
+    const uint8_t* src = frames;
+    long sstride = stride;
+    int sstep = step;
+    if (newW != cols || newH != rows) {
+        resized_.ensure((size_t)n * newH * newW * 3);
+        launch_resize_u8c3(frames, stride, rows, cols, step, resized_.as<uint8_t>(), (long)newH * newW * 3, newH, newW, newW * 3, n, s);
+        src = resized_.as<uint8_t>(); sstride = (long)newH * newW * 3; sstep = newW * 3;
+    }
+    launch_det_preprocess(src, sstride, rows, cols, sstep, n, inH, inW, newH, newW, net_.input(), s);
+    net_.run(n, s);
+}
+
+void Detector::postprocess_dev(int n, float score_thr, float nms_thr, FaceRec* out, int max_out, int* counts, hipStream_t s) {
+    if (anchors_ <= 0) { FH_HIP(hipMemsetAsync(counts, 0, (size_t)n * sizeof(int), s)); return; }
+    FH_HIP(hipMemsetAsync(count_.p, 0, (size_t)n * sizeof(int), s));
+    if (predecoded_) {
+        launch_rows_threshold(net_.output(0), n, anchors_, feat_, scale_, score_thr, cand_.as<FaceRec>(),
+                              keys_.as<unsigned long long>(), count_.as<int>(), cap_, s);
+    } else {
+        DecodeArgs a{};
+        for (int i = 0; i < 3; ++i) { a.score[i] = net_.output(i); a.bbox[i] = net_.output(3 + i); a.kps[i] = net_.output(6 + i); }
+        a.inH = net_.in_h(); a.inW = net_.in_w(); a.B = n; a.scale = scale_; a.thr = score_thr;
+        a.cand = cand_.as<FaceRec>(); a.keys = keys_.as<unsigned long long>(); a.count = count_.as<int>(); a.cap = cap_;
+        launch_scrfd_decode(a, s);
+    }
+    launch_sort_nms(cand_.as<FaceRec>(), keys_.as<unsigned long long>(), count_.as<int>(), cap_, n, nms_thr, out, counts, max_out,
+                    ws_.as<int>(), s);
+    FH_HIP(hipGetLastError());
+}
+
+void Detector::detect_dev(const uint8_t* frames, int n, int rows, int cols, int step, long stride, float score_thr, float nms_thr,
+                          FaceRec* out, int max_out, int* counts, hipStream_t s) {
+    if (n <= 0) return;
+    run_network_dev(frames, n, rows, cols, step, stride, s);
+    postprocess_dev(n, score_thr, nms_thr, out, max_out, counts, s);
+}
+
+// ------------------------------------------------------------------------------------------ Recognizer
+Recognizer::Recognizer(const std::string& onnx_path) : net_(onnx_path, 112, 112) {      // src/face_recognizer.cpp:8-9
+    const auto& o = net_.plan().outputs.at(0);
+    dim_ = o.rows * o.cols;                       // feature size comes from the output shape (:286-294)
+}
+
+void Recognizer::embed_aligned_dev(const uint8_t* crops, int n, float* out, hipStream_t s, float* raw_out) {
+    const int H = net_.in_h(), W = net_.in_w();
+    net_.reserve(std::min(n, max_chunk));
+    for (int off = 0; off < n; off += max_chunk) {
+        const int c = std::min(max_chunk, n - off);
+        launch_rec_preprocess(crops + (size_t)off * H * W * 3, c, H, W, net_.input(), s);
+        net_.run(c, s);
+        if (raw_out) FH_HIP(hipMemcpyAsync(raw_out + (size_t)off * dim_, net_.output(0), (size_t)c * dim_ * sizeof(float), hipMemcpyDeviceToDevice, s));
+        launch_l2_normalize(net_.output(0), out + (size_t)off * dim_, c, dim_, s);
+    }
+    FH_HIP(hipGetLastError());
+}
+
+void Recognizer::align_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces,
+                           const int* frame_of, int n, uint8_t* crops, int* ok, hipStream_t s) {
+    launch_align(frames, stride, rows, cols, step, faces, frame_of, n, net_.in_h(), net_.in_w(), crops, ok, s);
+    FH_HIP(hipGetLastError());
+}
+
+void Recognizer::embed_faces_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces,
+                                 const int* frame_of, int n, float* out, int* ok, hipStream_t s) {
+    if (n <= 0) return;
+    const size_t crop = (size_t)net_.in_h() * net_.in_w() * 3;
+    crops_.ensure((size_t)n * crop);
+    ok_.ensure((size_t)n * sizeof(int));
+    int* okp = ok ? ok : ok_.as<int>();
+    align_dev(frames, rows, cols, step, stride, faces, frame_of, n, crops_.as<uint8_t>(), okp, s);
+    embed_aligned_dev(crops_.as<uint8_t>(), n, out, s);
+}
+
+void Recognizer::resize_embed_dev(const uint8_t* frames, int n, int rows, int cols, int step, long stride, float* out, hipStream_t s) {
+    // extractFeatureSimple (src/face_recognizer.cpp:152-234): cv::resize the whole image to the input size
+    const int H = net_.in_h(), W = net_.in_w();
+    crops_.ensure((size_t)n * H * W * 3);
+    launch_resize_u8c3(frames, stride, rows, cols, step, crops_.as<uint8_t>(), (long)H * W * 3, H, W, W * 3, n, s);
+    embed_aligned_dev(crops_.as<uint8_t>(), n, out, s);
+}
+
+// ------------------------------------------------------------------------------------------ Gallery
+void Gallery::upload(const float* rows, long n, bool device_src, long index_base) {
+    if (dim_ % 32) throw std::runtime_error("gallery: dim must be a multiple of 32");
+    rows_.ensure((size_t)n * dim_ * sizeof(float));
+    FH_HIP(hipMemcpy(rows_.p, rows, (size_t)n * dim_ * sizeof(float), device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    n_ = n; base_ = index_base;
+}
+
+void Gallery::topk_dev(const float* q, int Q, int k, float* out_score, int* out_idx, hipStream_t s) {
+    if (Q <= 0 || Q > 256 || k <= 0 || k > 16) throw std::runtime_error("gallery: need 0 < Q <= 256 and 0 < k <= 16");
+    const long kSlab = 1L << 20;
+    const int nsub = 256 / Q;
+    const int wrows = conv_wt_rows(Q);
+    qpack_.ensure((size_t)wrows * dim_ * sizeof(float));
+    FH_HIP(hipMemsetAsync(qpack_.p, 0, (size_t)wrows * dim_ * sizeof(float), s));
+    FH_HIP(hipMemcpyAsync(qpack_.p, q, (size_t)Q * dim_ * sizeof(float), hipMemcpyDeviceToDevice, s));
+    dots_.ensure((size_t)std::min(kSlab, std::max(n_, 1L)) * Q * sizeof(float));
+    int parts_total = 0;
+    for (long r0 = 0; r0 < n_; r0 += kSlab) parts_total += gallery_blocks(std::min(kSlab, n_ - r0)) * nsub;
+    ps_.ensure((size_t)std::max(parts_total, 1) * Q * k * sizeof(float));
+    pi_.ensure((size_t)std::max(parts_total, 1) * Q * k * sizeof(int));
+    int part = 0;
+    for (long r0 = 0; r0 < n_; r0 += kSlab) {
+        const long g = std::min(kSlab, n_ - r0);
+        ConvArgs a{};
+        a.in = rows_.as<float>() + (size_t)r0 * dim_;
+        a.wt = qpack_.as<float>();
+        a.out1 = dots_.as<float>();
+        a.B = (int)g; a.H = a.W = a.Ho = a.Wo = 1; a.Cin = dim_; a.Cout = Q; a.ks = 1; a.stride = 1; a.pad = 0;
+        a.Kpad = dim_; a.nsplit = 1;
+        launch_conv(a, -1, s);
+        launch_topk_partial(dots_.as<float>(), g, Q, k, ps_.as<float>() + (size_t)part * Q * k, pi_.as<int>() + (size_t)part * Q * k,
+                            base_ + r0, s);
+        part += gallery_blocks(g) * nsub;
+    }
+    launch_topk_merge(ps_.as<float>(), pi_.as<int>(), parts_total, Q, k, out_score, out_idx, s);
+    FH_HIP(hipGetLastError());
+}
+
+}  // namespace fh

@@ -1,0 +1,120 @@
+// engine.h — device-side owner of one loaded graph (weights + activation arena + launch
+// sequence) and the detector / recognizer / gallery objects built on it.  These are the
+// objects behind the opaque C handles of include/facehip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "plan.h"
+
+namespace fh {
+
+void hip_check(hipError_t e, const char* what);
+#define FH_HIP(x) ::fh::hip_check((x), #x)
+
+struct DevBuf {                // owning hipMalloc buffer
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf();
+    void ensure(size_t n);     // grow-only (re)allocation
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// One ONNX graph planned for a fixed input size, resident on the current device.
+class Net {
+  public:
+    Net(const std::string& onnx_path, int default_h, int default_w);
+    void reserve(int max_batch);                          // arena + split-K slabs for this batch
+    float* input() const { return arena_.as<float>() + plan_.tensors[plan_.input].offset * (size_t)cap_; }
+    float* output(int i) const { return tensor_ptr(plan_.outputs[i].tensor); }
+    void run(int batch, hipStream_t s);
+    const Plan& plan() const { return plan_; }
+    int in_h() const { return plan_.inH; }
+    int in_w() const { return plan_.inW; }
+    int capacity() const { return cap_; }
+    int force_cfg = -1;                                   // tuning hook: conv tile config override
+
+  private:
+    struct DevOp {
+        size_t wt = 0, bias = 0, slope = 0, s2 = 0, t2 = 0;   // float offsets into params_
+        bool has_slope = false, has_aff = false;
+        int Kpad = 0;
+    };
+    float* tensor_ptr(int t) const { return arena_.as<float>() + plan_.tensors[t].offset * (size_t)cap_; }
+    int pick_split(const POp& op, int batch, int cfg) const;
+    Plan plan_;
+    std::vector<DevOp> dev_;
+    DevBuf params_, arena_, partial_;
+    int cap_ = 0;
+};
+
+class Detector {
+  public:
+    explicit Detector(const std::string& onnx_path);
+    // frames: device pointer, n images of rows x cols BGR u8 (row pitch `step`, image pitch `stride`)
+    // out: device [n][max_out] FaceRec, counts: device [n].  Asynchronous on stream s.
+    void detect_dev(const uint8_t* frames, int n, int rows, int cols, int step, long stride, float score_thr, float nms_thr,
+                    FaceRec* out, int max_out, int* counts, hipStream_t s);
+    // network + decode only, for tests: rows15 = device [n][N][15]? not needed — outputs are read through net()
+    Net& net() { return net_; }
+    int num_anchors() const { return anchors_; }
+    bool predecoded() const { return predecoded_; }
+    float last_scale() const { return scale_; }
+    // stage hooks used by parity tests (device pointers)
+    void run_network_dev(const uint8_t* frames, int n, int rows, int cols, int step, long stride, hipStream_t s);
+    void postprocess_dev(int n, float score_thr, float nms_thr, FaceRec* out, int max_out, int* counts, hipStream_t s);
+
+  private:
+    void reserve(int n, int rows, int cols);
+    Net net_;
+    bool predecoded_ = false;
+    int anchors_ = 0, feat_ = 15, cap_ = 0, nb_ = 0;
+    float scale_ = 1.f;
+    DevBuf resized_, cand_, keys_, count_, ws_;
+};
+
+class Recognizer {
+  public:
+    explicit Recognizer(const std::string& onnx_path);
+    int dim() const { return dim_; }
+    Net& net() { return net_; }
+    // aligned crops [n][H][W][3] BGR u8 (device) -> L2-normalised embeddings [n][dim] (device)
+    void embed_aligned_dev(const uint8_t* crops, int n, float* out, hipStream_t s, float* raw_out = nullptr);
+    // alignFace + embed: faces[n] (device) on frames; ok[n] (device, may be null) 1/2 = produced, 0 = empty
+    void embed_faces_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces,
+                         const int* frame_of, int n, float* out, int* ok, hipStream_t s);
+    void align_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces, const int* frame_of,
+                   int n, uint8_t* crops, int* ok, hipStream_t s);
+    void resize_embed_dev(const uint8_t* frames, int n, int rows, int cols, int step, long stride, float* out, hipStream_t s);
+    int max_chunk = 256;                                 // faces per network pass
+
+  private:
+    Net net_;
+    int dim_ = 0;
+    DevBuf crops_, ok_, raw_;
+};
+
+class Gallery {
+  public:
+    explicit Gallery(int dim) : dim_(dim) {}
+    void upload(const float* rows, long n, bool device_src, long index_base);
+    // queries [Q][dim] device, Q <= 256, k <= 16 -> out_score/out_idx [Q][k] device
+    void topk_dev(const float* q, int Q, int k, float* out_score, int* out_idx, hipStream_t s);
+    long size() const { return n_; }
+    int dim() const { return dim_; }
+
+  private:
+    int dim_;
+    long n_ = 0, base_ = 0;
+    DevBuf rows_, qpack_, dots_, ps_, pi_;
+};
+
+}  // namespace fh

@@ -1,0 +1,109 @@
+// kernels.h — host-side launch interface of the gfx950 kernels (device pointers only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace fh {
+
+// --------------------------------------------------------------------------------------------
+// Dense convolution / FC as implicit GEMM on v_mfma_f32_32x32x2_f32 (conv_mfma.hip)
+//   M = B*Ho*Wo output pixels, N = Cout, K = ks*ks*Cin (k = tap*Cin + ci), all fp32, NHWC.
+// --------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* in;        // [B,H,W,Cin]
+    const float* wt;        // packed [CoutPad][Kpad], rows >= Cout and cols >= Ktot are zero
+    const float* bias;      // [Cout]
+    const float* slope;     // [Cout] (PReLU) or null
+    const float* res;       // residual [B,Ho,Wo,Cout] (SAME) / [B,Ho/2,Wo/2,Cout] (UP2X) or null
+    float* out1;            // [B,Ho,Wo,Cout] or null
+    float* out2;            // second output  out*s2 + t2, or null
+    const float* s2;
+    const float* t2;
+    float* partial;         // split-K slabs [nsplit][M][Cout] (only when nsplit > 1)
+    int B, H, W, Cin, Ho, Wo, Cout;
+    int ks, stride, pad;
+    int Kpad;               // multiple of 32
+    int act;                // fh::Act
+    int res_mode;           // fh::ResMode
+    int nsplit;             // >= 1
+};
+
+// cfg: 0 = 128x128 tile, 1 = 256x64, 2 = 128x32, 3 = 64x64 (256 threads each); -1 = choose.
+void launch_conv(const ConvArgs& a, int cfg, hipStream_t s);
+int conv_pick_cfg(long M, int Cout);
+int conv_wt_rows(int Cout);                   // packed weight rows (Cout rounded up to 128)
+inline int conv_kpad(int Ktot) { return (Ktot + 31) / 32 * 32; }
+
+// --------------------------------------------------------------------------------------------
+// Bandwidth-bound graph ops (ops_misc.hip)
+// --------------------------------------------------------------------------------------------
+void launch_dwconv3x3(const float* in, const float* w9c, const float* bias, float* out, int B, int H, int W,
+                      int C, int stride, int act, hipStream_t s);
+void launch_affine(const float* in, const float* sc, const float* sh, float* out, long pixels, int C, hipStream_t s);
+void launch_act(const float* in, const float* slope, float* out, long pixels, int C, int act, hipStream_t s);
+void launch_add(const float* a, const float* b, float* out, long n, hipStream_t s);
+void launch_upsample2x(const float* in, float* out, int B, int H, int W, int C, hipStream_t s);
+
+// --------------------------------------------------------------------------------------------
+// Non-NN kernels of the face path (face_kernels.hip)
+// --------------------------------------------------------------------------------------------
+struct FaceRec {            // POD mirror of reference struct FaceBox (src/face_detector.h:8-12), 60 B
+    int32_t x, y, w, h;
+    float score;
+    float lm[10];
+};
+
+// FaceDetector::preprocess (src/face_detector.cpp:92-137) → NHWC4 fp32 [B,inH,inW,4]
+//   frames: B images, each rows x cols BGR u8 with row pitch `step` bytes and image pitch `img_stride`.
+void launch_det_preprocess(const uint8_t* frames, long img_stride, int rows, int cols, int step, int B,
+                           int inH, int inW, int newH, int newW, float* out, hipStream_t s);
+// FaceRecognizer::preprocess (src/face_recognizer.cpp:135-150) on aligned crops → NHWC4
+void launch_rec_preprocess(const uint8_t* crops, int n, int H, int W, float* out, hipStream_t s);
+
+struct DecodeArgs {
+    const float* score[3];  // per stride [B, gh*gw*2]
+    const float* bbox[3];   // [B, gh*gw*2, 4]
+    const float* kps[3];    // [B, gh*gw*2, 10]
+    int inH, inW, B;
+    float scale, thr;
+    FaceRec* cand;          // [B][cap]
+    unsigned long long* keys;   // [B][cap]  sort keys (score desc, anchor index asc)
+    int* count;             // [B]
+    int cap;
+};
+void launch_scrfd_decode(const DecodeArgs& a, hipStream_t s);
+// generic [rows, feat>=15] pre-decoded layout (src/face_detector.cpp:242-325)
+void launch_rows_threshold(const float* rows, int B, int n, int feat, float scale, float thr, FaceRec* cand,
+                           unsigned long long* keys, int* count, int cap, hipStream_t s);
+// sort by key + greedy integer-IoU NMS (src/face_detector.cpp:340-384); writes survivors
+// (score-descending) to out[B][max_out], counts to out_count[B].
+void launch_sort_nms(const FaceRec* cand, unsigned long long* keys, const int* count, int cap, int B, float nms_thr,
+                     FaceRec* out, int* out_count, int max_out, int* order_ws, hipStream_t s);
+
+// FaceRecognizer::alignFace (src/face_recognizer.cpp:93-133): similarity estimate + warpAffine
+//   faces[n] with frame index frame_of[n]; writes crops [n,112,112,3] BGR u8 and ok[n].
+void launch_align(const uint8_t* frames, long img_stride, int rows, int cols, int step, const FaceRec* faces,
+                  const int* frame_of, int n, int outH, int outW, uint8_t* crops, int* ok, hipStream_t s);
+void launch_resize_u8c3(const uint8_t* src, long src_stride, int sh, int sw, int sstep, uint8_t* dst, long dst_stride,
+                        int dh, int dw, int dstep, int n, hipStream_t s);
+
+// FaceRecognizer::normalize (src/face_recognizer.cpp:306-318), one wave per row
+void launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_t s);
+// FC split-K finish: sum slabs + bias → raw; (src/face_recognizer.cpp:286-297)
+void launch_splitk_finish(const ConvArgs& a, hipStream_t s);
+
+// compareFaces generalised to 1:N (src/face_recognizer.cpp:320-334): top-k of (dot+1)/2 ranked
+// (score desc, gallery index asc).  dots = [G][Q] raw dot products from launch_conv (gallery rows
+// as GEMM-M, queries as GEMM-N); partial lists [gallery_blocks(G)*(256/Q)][Q][k] then one merge.
+void launch_topk_partial(const float* dots, long G, int Q, int k, float* part_score, int* part_idx, long idx_base,
+                         hipStream_t s);
+void launch_topk_merge(const float* part_score, const int* part_idx, int nparts, int Q, int k, float* out_score,
+                       int* out_idx, hipStream_t s);
+int gallery_blocks(long G);
+
+// detect -> embed hand-off: first min(count,F) faces per frame, densely packed (n <= 4096 frames)
+void launch_select_faces(const FaceRec* det, const int* counts, int n, int per_frame, int F, FaceRec* faces, int* frame_of,
+                         int* total, hipStream_t s);
+
+}  // namespace fh

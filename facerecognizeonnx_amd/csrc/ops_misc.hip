@@ -1,0 +1,118 @@
+// ops_misc.hip — the bandwidth-bound graph operators of the SCRFD / IResNet plans that are not
+// MFMA work: depthwise 3x3 convolution (+bias +ReLU), stand-alone BatchNormalization (affine),
+// stand-alone activations, Add and nearest 2x up-sampling.  All tensors are channels-last fp32,
+// every lane moves 16 bytes (4 channels) per access so a wave covers whole 128-byte lines.
+// These are the ONNX nodes ORT runs inside session_->Run (reference src/face_detector.cpp:179-183).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "plan.h"
+
+namespace fh {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+static inline int grid_for(long n, int block = 256, int cap = 256 * 16) {
+    long b = (n + block - 1) / block;
+    return (int)(b < 1 ? 1 : b > cap ? cap : b);
+}
+
+__device__ __forceinline__ float act1(float v, int act, float slope) {
+    if (act == (int)Act::RELU) return v > 0.f ? v : 0.f;
+    if (act == (int)Act::PRELU) return v >= 0.f ? v : v * slope;
+    if (act == (int)Act::SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int B, int H, int W, int C, int Ho, int Wo, int stride, int act) {
+    const int C4 = C >> 2;
+    const long total = (long)B * Ho * Wo * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        long pix = idx / C4;
+        const int ox = (int)(pix % Wo); pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        v4f acc = *reinterpret_cast<const v4f*>(bias + c4 * 4);
+        const int iy0 = oy * stride - 1, ix0 = ox * stride - 1;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = iy0 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ix0 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const v4f x = *reinterpret_cast<const v4f*>(in + (((size_t)n * H + iy) * W + ix) * C + c4 * 4);
+                const v4f ww = *reinterpret_cast<const v4f*>(w + (ky * 3 + kx) * C + c4 * 4);
+                acc += x * ww;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = act1(acc[e], act, 0.f);
+        *reinterpret_cast<v4f*>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4) = acc;
+    }
+}
+
+void launch_dwconv3x3(const float* in, const float* w9c, const float* bias, float* out, int B, int H, int W, int C,
+                      int stride, int act, hipStream_t s) {
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const long total = (long)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo,
+                       stride, act);
+}
+
+// generic per-channel pass, scalar channel indexing (C need not be a multiple of 4)
+__global__ __launch_bounds__(256) void affine_kernel(const float* __restrict__ in, const float* __restrict__ sc,
+                                                     const float* __restrict__ sh, float* __restrict__ out, long total, int C) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        out[i] = in[i] * sc[c] + sh[c];
+    }
+}
+void launch_affine(const float* in, const float* sc, const float* sh, float* out, long pixels, int C, hipStream_t s) {
+    const long total = pixels * C;
+    hipLaunchKernelGGL(affine_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, sc, sh, out, total, C);
+}
+
+__global__ __launch_bounds__(256) void act_kernel(const float* __restrict__ in, const float* __restrict__ slope,
+                                                  float* __restrict__ out, long total, int C, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float sl = slope ? slope[i % C] : 0.f;
+        out[i] = act1(in[i], act, sl);
+    }
+}
+void launch_act(const float* in, const float* slope, float* out, long pixels, int C, int act, hipStream_t s) {
+    const long total = pixels * C;
+    hipLaunchKernelGGL(act_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, slope, out, total, C, act);
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+void launch_add(const float* a, const float* b, float* out, long n, hipStream_t s) {
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, b, out, n);
+}
+
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H,
+                                                         int W, int C) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long total = (long)B * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long pix = i / C;
+        const int ox = (int)(pix % Wo); pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        out[i] = in[(((size_t)n * H + (oy >> 1)) * W + (ox >> 1)) * C + c];
+    }
+}
+void launch_upsample2x(const float* in, float* out, int B, int H, int W, int C, hipStream_t s) {
+    const long total = (long)B * 4 * H * W * C;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, B, H, W, C);
+}
+
+}  // namespace fh

@@ -1,0 +1,528 @@
+// plan.cpp — fusion + layout planning.  See plan.h.
+//
+// Fusions (each only when the intermediate value has exactly one consumer):
+//   Conv/Gemm -> BatchNormalization          folded into weights/bias (fp64 on the host)
+//   Conv -> Relu | PRelu | Sigmoid           epilogue activation
+//   Conv (-> act) -> Add(other)              epilogue residual (order: bias, act, + residual)
+//   ... Add(conv, Resize_nearest_x2(t))      residual read through a 2x nearest up-sampling
+//   X -> BatchNormalization -> zero-padded Conv   (IResNet `bn1`): cannot be
+//        folded into the conv exactly (border taps see 0, not the BN shift), so the BN is
+//        emitted as a SECOND output of the kernel that produces X.
+//   Transpose(0,2,3,1) / Reshape / Flatten   views of the channels-last storage; the Gemm
+//        after an NCHW Flatten gets its K axis permuted instead.
+#include "plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <map>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+
+namespace fh {
+namespace {
+
+struct GNode {
+    std::string op;
+    std::vector<std::string> in;
+    std::string out;
+    const OnnxNode* src = nullptr;
+    bool dead = false;
+    int order = 0;
+    // conv / gemm payload
+    std::vector<double> w;                 // ONNX layout
+    std::vector<double> b;
+    int Cout = 0, CinG = 0, ks = 1, stride = 1, pad = 0, group = 1;
+    // fused
+    Act act = Act::NONE;
+    std::vector<float> slope;
+    std::string res;
+    ResMode res_mode = ResMode::NONE;
+    std::string out2;
+    std::vector<float> s2, t2;
+    bool write_out1 = true;
+};
+
+[[noreturn]] void fail(const std::string& msg) { throw std::runtime_error("plan: " + msg); }
+
+const OnnxTensor& init_of(const OnnxModel& m, const std::string& name) {
+    auto it = m.inits.find(name);
+    if (it == m.inits.end()) fail("expected initializer '" + name + "'");
+    return it->second;
+}
+
+void bn_scale_shift(const OnnxModel& m, const OnnxNode& bn, std::vector<double>& s, std::vector<double>& t) {
+    const auto& g = init_of(m, bn.inputs[1]).f;
+    const auto& be = init_of(m, bn.inputs[2]).f;
+    const auto& mu = init_of(m, bn.inputs[3]).f;
+    const auto& var = init_of(m, bn.inputs[4]).f;
+    const double eps = bn.attr_f("epsilon", 1e-5f);
+    size_t c = g.size();
+    if (be.size() != c || mu.size() != c || var.size() != c) fail("BatchNormalization parameter size mismatch");
+    s.resize(c); t.resize(c);
+    for (size_t i = 0; i < c; ++i) {
+        s[i] = (double)g[i] / std::sqrt((double)var[i] + eps);
+        t[i] = (double)be[i] - (double)mu[i] * s[i];
+    }
+}
+
+// how an ONNX value maps onto stored tensors
+struct Val {
+    int tensor = -1;
+    enum Kind { NCHW4D, NHWC4D, FLAT_NCHW, FLAT_STORAGE } kind = NCHW4D;
+    int rows = 0, cols = 0;     // FLAT_STORAGE view (per image)
+};
+
+}  // namespace
+
+Plan build_plan(const OnnxModel& m, int inH, int inW) {
+    if (m.inputs.size() != 1) fail("expected exactly one graph input");
+    // ---------------------------------------------------------------- 1. node list
+    std::vector<GNode> g;
+    g.reserve(m.nodes.size());
+    int ord = 0;
+    for (const auto& n : m.nodes) {
+        GNode x;
+        x.op = n.op; x.src = &n; x.order = ord++;
+        if (n.outputs.empty()) fail("node without output");
+        x.out = n.outputs[0];
+        if (n.op == "Conv") {
+            const auto& w = init_of(m, n.inputs.at(1));
+            if (w.dims.size() != 4 || w.dims[2] != w.dims[3]) fail("Conv weight must be [Cout,Cin/g,k,k]");
+            x.Cout = (int)w.dims[0]; x.CinG = (int)w.dims[1]; x.ks = (int)w.dims[2];
+            x.group = (int)n.attr_i("group", 1);
+            auto st = n.attr_ints("strides"); auto pd = n.attr_ints("pads"); auto dl = n.attr_ints("dilations");
+            x.stride = st.empty() ? 1 : (int)st[0];
+            if (!st.empty() && st[0] != st[1]) fail("anisotropic stride");
+            x.pad = pd.empty() ? 0 : (int)pd[0];
+            for (auto p : pd) if (p != x.pad) fail("asymmetric padding");
+            for (auto d : dl) if (d != 1) fail("dilation != 1");
+            if (n.attr_s("auto_pad", "NOTSET") != "NOTSET") fail("auto_pad not supported");
+            if (!((x.ks == 3 && x.pad == 1) || (x.ks == 1 && x.pad == 0))) fail("only 3x3/p1 and 1x1/p0 convolutions are supported");
+            x.w.assign(w.f.begin(), w.f.end());
+            if (n.inputs.size() > 2 && !n.inputs[2].empty()) { const auto& b = init_of(m, n.inputs[2]).f; x.b.assign(b.begin(), b.end()); }
+            else x.b.assign((size_t)x.Cout, 0.0);
+            x.in = {n.inputs[0]};
+        } else if (n.op == "Gemm") {
+            const auto& w = init_of(m, n.inputs.at(1));
+            if (w.dims.size() != 2) fail("Gemm weight must be 2-D");
+            if (n.attr_i("transB", 0) != 1 || n.attr_i("transA", 0) != 0 || n.attr_f("alpha", 1.f) != 1.f || n.attr_f("beta", 1.f) != 1.f)
+                fail("Gemm: only alpha=beta=1, transB=1 supported");
+            x.Cout = (int)w.dims[0]; x.CinG = (int)w.dims[1];
+            x.w.assign(w.f.begin(), w.f.end());
+            if (n.inputs.size() > 2 && !n.inputs[2].empty()) { const auto& b = init_of(m, n.inputs[2]).f; x.b.assign(b.begin(), b.end()); }
+            else x.b.assign((size_t)x.Cout, 0.0);
+            x.in = {n.inputs[0]};
+        } else if (n.op == "BatchNormalization" || n.op == "Relu" || n.op == "Sigmoid" || n.op == "Flatten" ||
+                   n.op == "Transpose" || n.op == "Reshape" || n.op == "PRelu" || n.op == "Resize" || n.op == "Upsample") {
+            x.in = {n.inputs[0]};
+        } else if (n.op == "Add") {
+            x.in = {n.inputs.at(0), n.inputs.at(1)};
+            if (m.inits.count(x.in[0]) || m.inits.count(x.in[1])) fail("Add with a constant operand is not supported");
+        } else {
+            fail("unsupported operator '" + n.op + "'");
+        }
+        g.push_back(std::move(x));
+    }
+
+    std::set<std::string> graph_outs;
+    for (auto& o : m.outputs) graph_outs.insert(o.name);
+    auto consumers = [&](const std::string& v) {
+        int c = graph_outs.count(v) ? 1 : 0;
+        for (auto& n : g) {
+            if (n.dead) continue;
+            for (auto& i : n.in) if (i == v) ++c;
+            if (n.res == v) ++c;
+        }
+        return c;
+    };
+    auto producer = [&](const std::string& v) -> GNode* {
+        for (auto& n : g) if (!n.dead && (n.out == v || (!n.out2.empty() && n.out2 == v))) return &n;
+        return nullptr;
+    };
+    auto is_convlike = [](const GNode* n) { return n && (n->op == "Conv" || n->op == "Gemm"); };
+    auto resize_is_up2 = [&](const GNode& r) {
+        const OnnxNode& n = *r.src;
+        if (n.attr_s("mode", "nearest") != "nearest") fail("Resize: only nearest supported");
+        if (n.op == "Upsample" || (n.inputs.size() > 2 && !n.inputs[2].empty() && init_of(m, n.inputs[2]).f.size() == 4)) {
+            const auto& sc = init_of(m, n.op == "Upsample" ? n.inputs.at(1) : n.inputs[2]).f;
+            return sc[0] == 1.f && sc[1] == 1.f && sc[2] == 2.f && sc[3] == 2.f;
+        }
+        fail("Resize: only constant scales [1,1,2,2] supported (shape sub-graphs are not folded yet)");
+    };
+
+    // ---------------------------------------------------------------- 2. Conv/Gemm -> BN folding
+    for (auto& bn : g) {
+        if (bn.dead || bn.op != "BatchNormalization") continue;
+        GNode* p = producer(bn.in[0]);
+        if (!is_convlike(p) || p->out != bn.in[0] || consumers(p->out) != 1) continue;
+        if (p->act != Act::NONE || !p->res.empty() || !p->out2.empty()) continue;
+        std::vector<double> s, t;
+        bn_scale_shift(m, *bn.src, s, t);
+        if ((int)s.size() != p->Cout) fail("BN channel mismatch after " + p->op);
+        size_t per = p->w.size() / (size_t)p->Cout;
+        for (int co = 0; co < p->Cout; ++co) {
+            for (size_t k = 0; k < per; ++k) p->w[(size_t)co * per + k] *= s[co];
+            p->b[co] = p->b[co] * s[co] + t[co];
+        }
+        p->out = bn.out;
+        bn.dead = true;
+    }
+    // ---------------------------------------------------------------- 3. activation fusion
+    for (auto& a : g) {
+        if (a.dead || !(a.op == "Relu" || a.op == "PRelu" || a.op == "Sigmoid")) continue;
+        GNode* p = producer(a.in[0]);
+        if (!p || p->op != "Conv" || p->out != a.in[0] || consumers(p->out) != 1) continue;
+        if (p->act != Act::NONE || !p->res.empty() || !p->out2.empty()) continue;
+        if (a.op == "Relu") p->act = Act::RELU;
+        else if (a.op == "Sigmoid") p->act = Act::SIGMOID;
+        else {
+            const auto& sl = init_of(m, a.src->inputs.at(1)).f;
+            if (sl.size() == 1) p->slope.assign((size_t)p->Cout, sl[0]);
+            else if ((int)sl.size() == p->Cout) p->slope = sl;
+            else fail("PRelu slope size mismatch");
+            p->act = Act::PRELU;
+        }
+        p->out = a.out;
+        a.dead = true;
+    }
+    // ---------------------------------------------------------------- 4. residual (Add) fusion
+    for (auto& add : g) {
+        if (add.dead || add.op != "Add") continue;
+        for (int side = 0; side < 2; ++side) {
+            GNode* p = producer(add.in[side]);
+            if (!p || p->op != "Conv" || p->group != 1 || p->out != add.in[side]) continue;
+            if (consumers(p->out) != 1 || !p->res.empty() || !p->out2.empty()) continue;
+            const std::string other = add.in[1 - side];
+            if (other == p->out) continue;
+            GNode* q = producer(other);
+            if (q && (q->op == "Resize" || q->op == "Upsample") && consumers(q->out) == 1 && resize_is_up2(*q)) {
+                p->res = q->in[0]; p->res_mode = ResMode::UP2X; q->dead = true;
+            } else {
+                p->res = other; p->res_mode = ResMode::SAME;
+            }
+            p->out = add.out;
+            add.dead = true;
+            break;
+        }
+    }
+    // ---------------------------------------------------------------- 5. BN as second output
+    for (auto& bn : g) {
+        if (bn.dead || bn.op != "BatchNormalization") continue;
+        GNode* p = producer(bn.in[0]);
+        if (!p || p->op != "Conv" || p->group != 1 || p->out != bn.in[0] || !p->out2.empty()) continue;
+        std::vector<double> s, t;
+        bn_scale_shift(m, *bn.src, s, t);
+        if ((int)s.size() != p->Cout) fail("BN channel mismatch (second output)");
+        p->s2.assign(s.begin(), s.end());
+        p->t2.assign(t.begin(), t.end());
+        p->out2 = bn.out;
+        bn.dead = true;
+        if (consumers(p->out) == 0) p->write_out1 = false;
+    }
+
+    // ---------------------------------------------------------------- 6. topological order
+    std::vector<GNode*> live;
+    for (auto& n : g) if (!n.dead) live.push_back(&n);
+    std::vector<GNode*> sorted;
+    {
+        std::set<std::string> ready;
+        ready.insert(m.inputs[0].name);
+        std::vector<bool> done(live.size(), false);
+        for (size_t iter = 0; iter < live.size(); ++iter) {
+            bool progressed = false;
+            for (size_t i = 0; i < live.size(); ++i) {
+                if (done[i]) continue;
+                GNode* n = live[i];
+                bool ok = true;
+                for (auto& v : n->in) if (!ready.count(v)) ok = false;
+                if (!n->res.empty() && !ready.count(n->res)) ok = false;
+                if (!ok) continue;
+                done[i] = true; progressed = true;
+                sorted.push_back(n);
+                ready.insert(n->out);
+                if (!n->out2.empty()) ready.insert(n->out2);
+                break;               // restart scan → stable w.r.t. file order
+            }
+            if (!progressed) fail("graph is not a DAG over the supported ops (unresolved input)");
+        }
+    }
+
+    // ---------------------------------------------------------------- 7. shapes, views, ops
+    Plan P;
+    P.inH = inH; P.inW = inW;
+    std::map<std::string, Val> vals;
+    auto new_tensor = [&](const std::string& name, int H, int W, int C) {
+        PTensor t; t.name = name; t.H = H; t.W = W; t.C = C;
+        P.tensors.push_back(t);
+        return (int)P.tensors.size() - 1;
+    };
+    {
+        const auto& shp = m.inputs[0].shape;
+        if (shp.size() != 4) fail("graph input must be 4-D NCHW");
+        if (shp[1] > 0 && shp[1] != 3) fail("graph input must have 3 channels");
+        P.input = new_tensor(m.inputs[0].name, inH, inW, 4);      // RGB + one zero lane
+        P.tensors[P.input].is_input = true;
+        Val v; v.tensor = P.input; v.kind = Val::NCHW4D;
+        vals[m.inputs[0].name] = v;
+    }
+    auto need4d = [&](const std::string& name) -> const Val& {
+        auto it = vals.find(name);
+        if (it == vals.end()) fail("value '" + name + "' used before definition");
+        if (it->second.kind != Val::NCHW4D) fail("operator needs a 4-D NCHW value: '" + name + "'");
+        return it->second;
+    };
+
+    for (GNode* n : sorted) {
+        if (n->op == "Conv") {
+            const Val& vi = need4d(n->in[0]);
+            const PTensor ti = P.tensors[vi.tensor];
+            const int logicalCin = n->CinG * n->group;
+            const bool is_input = vi.tensor == P.input;
+            if (!(ti.C == logicalCin || (is_input && logicalCin == 3))) fail("Conv input channel mismatch at " + n->out);
+            POp op;
+            op.name = n->src->name.empty() ? n->out : n->src->name;
+            op.in = vi.tensor; op.ks = n->ks; op.stride = n->stride; op.pad = n->pad;
+            op.H = ti.H; op.W = ti.W; op.Cin = ti.C; op.Cout = n->Cout;
+            op.Ho = (ti.H + 2 * n->pad - n->ks) / n->stride + 1;
+            op.Wo = (ti.W + 2 * n->pad - n->ks) / n->stride + 1;
+            op.act = n->act; op.slope = n->slope;
+            op.bias.assign(n->b.begin(), n->b.end());
+            const int taps = n->ks * n->ks;
+            if (n->group == 1) {
+                op.kind = OpKind::CONV;
+                op.weight.assign((size_t)n->Cout * taps * ti.C, 0.f);
+                for (int co = 0; co < n->Cout; ++co)
+                    for (int ci = 0; ci < logicalCin; ++ci)
+                        for (int t = 0; t < taps; ++t)
+                            op.weight[((size_t)co * taps + t) * ti.C + ci] =
+                                (float)n->w[((size_t)co * logicalCin + ci) * taps + t];
+                op.macs = (double)op.Ho * op.Wo * n->Cout * taps * logicalCin;
+            } else {
+                if (!(n->group == logicalCin && n->CinG == 1 && n->Cout == logicalCin && n->ks == 3))
+                    fail("grouped Conv other than depthwise 3x3 is not supported");
+                if (ti.C % 4) fail("depthwise Conv needs C % 4 == 0");
+                if (!n->res.empty() || !n->out2.empty()) fail("internal: fused residual on depthwise");
+                op.kind = OpKind::DWCONV;
+                op.weight.assign((size_t)9 * ti.C, 0.f);
+                for (int c = 0; c < ti.C; ++c)
+                    for (int t = 0; t < 9; ++t) op.weight[(size_t)t * ti.C + c] = (float)n->w[(size_t)c * 9 + t];
+                op.macs = (double)op.Ho * op.Wo * ti.C * 9;
+            }
+            if (op.kind == OpKind::CONV && ti.C % 4) fail("Conv needs stored Cin % 4 == 0 at " + n->out);
+            if (n->write_out1) {
+                op.out = new_tensor(n->out, op.Ho, op.Wo, n->Cout);
+                Val v; v.tensor = op.out; vals[n->out] = v;
+            }
+            if (!n->out2.empty()) {
+                op.out2 = new_tensor(n->out2, op.Ho, op.Wo, n->Cout);
+                op.s2 = n->s2; op.t2 = n->t2;
+                Val v; v.tensor = op.out2; vals[n->out2] = v;
+            }
+            if (!n->res.empty()) {
+                const Val& vr = need4d(n->res);
+                const PTensor& tr = P.tensors[vr.tensor];
+                op.res = vr.tensor; op.res_mode = n->res_mode;
+                const int f = n->res_mode == ResMode::UP2X ? 2 : 1;
+                if (tr.C != n->Cout || tr.H * f != op.Ho || tr.W * f != op.Wo) fail("residual shape mismatch at " + n->out);
+            }
+            P.ops.push_back(std::move(op));
+        } else if (n->op == "Gemm") {
+            auto it = vals.find(n->in[0]);
+            if (it == vals.end()) fail("Gemm input undefined");
+            const Val vi = it->second;
+            const PTensor ti = P.tensors[vi.tensor];
+            const int K = n->CinG;
+            if ((size_t)K != ti.elems()) fail("Gemm K does not match the flattened producer");
+            POp op; op.kind = OpKind::GEMM; op.name = n->src->name.empty() ? n->out : n->src->name;
+            op.in = vi.tensor; op.ks = 1; op.stride = 1; op.pad = 0; op.H = op.W = op.Ho = op.Wo = 1;
+            op.Cin = K; op.Cout = n->Cout;
+            op.bias.assign(n->b.begin(), n->b.end());
+            op.weight.resize((size_t)n->Cout * K);
+            const int HW = ti.H * ti.W, Cc = ti.C;
+            const bool permute = vi.kind == Val::FLAT_NCHW && HW > 1;
+            if (!(vi.kind == Val::FLAT_NCHW || vi.kind == Val::FLAT_STORAGE)) fail("Gemm expects a flattened input");
+            for (int o = 0; o < n->Cout; ++o)
+                for (int k = 0; k < K; ++k) {
+                    int src = k;                               // storage index k = hw*C + c
+                    if (permute) { int hw = k / Cc, c = k % Cc; src = c * HW + hw; }
+                    op.weight[(size_t)o * K + k] = (float)n->w[(size_t)o * K + src];
+                }
+            op.macs = (double)K * n->Cout;
+            op.out = new_tensor(n->out, 1, 1, n->Cout);
+            Val v; v.tensor = op.out; v.kind = Val::FLAT_STORAGE; v.rows = 1; v.cols = n->Cout;
+            vals[n->out] = v;
+            P.ops.push_back(std::move(op));
+        } else if (n->op == "BatchNormalization") {
+            auto it = vals.find(n->in[0]);
+            if (it == vals.end()) fail("BN input undefined");
+            const Val vi = it->second;
+            const PTensor ti = P.tensors[vi.tensor];
+            std::vector<double> s, t;
+            bn_scale_shift(m, *n->src, s, t);
+            POp op; op.kind = OpKind::AFFINE; op.name = n->out; op.in = vi.tensor;
+            op.H = op.Ho = ti.H; op.W = op.Wo = ti.W; op.Cin = op.Cout = ti.C;
+            if (vi.kind == Val::NCHW4D) {
+                if (!((int)s.size() == ti.C || (vi.tensor == P.input && s.size() == 3))) fail("standalone BN channel mismatch");
+                s.resize(ti.C, 0.0); t.resize(ti.C, 0.0);
+            } else {
+                if ((int)s.size() != (vi.kind == Val::FLAT_STORAGE ? vi.cols : ti.C) || ti.H * ti.W != 1) fail("standalone BN on a flattened value needs H=W=1");
+            }
+            op.s2.assign(s.begin(), s.end()); op.t2.assign(t.begin(), t.end());
+            op.out = new_tensor(n->out, ti.H, ti.W, ti.C);
+            Val v = vi; v.tensor = op.out; vals[n->out] = v;
+            P.ops.push_back(std::move(op));
+        } else if (n->op == "Relu" || n->op == "Sigmoid" || n->op == "PRelu") {
+            const Val& vi = need4d(n->in[0]);
+            const PTensor ti = P.tensors[vi.tensor];
+            POp op; op.kind = OpKind::ACT; op.name = n->out; op.in = vi.tensor;
+            op.H = op.Ho = ti.H; op.W = op.Wo = ti.W; op.Cin = op.Cout = ti.C;
+            op.act = n->op == "Relu" ? Act::RELU : n->op == "Sigmoid" ? Act::SIGMOID : Act::PRELU;
+            if (op.act == Act::PRELU) {
+                const auto& sl = init_of(m, n->src->inputs.at(1)).f;
+                if (sl.size() == 1) op.slope.assign((size_t)ti.C, sl[0]); else op.slope = sl;
+                op.slope.resize(ti.C, 0.f);
+            }
+            op.out = new_tensor(n->out, ti.H, ti.W, ti.C);
+            Val v; v.tensor = op.out; vals[n->out] = v;
+            P.ops.push_back(std::move(op));
+        } else if (n->op == "Add") {
+            const Val va = need4d(n->in[0]);
+            const Val vb = need4d(n->in[1]);
+            const PTensor ta = P.tensors[va.tensor], tb = P.tensors[vb.tensor];
+            if (ta.H != tb.H || ta.W != tb.W || ta.C != tb.C) fail("Add operands differ in shape (broadcast unsupported)");
+            POp op; op.kind = OpKind::ADD; op.name = n->out; op.in = va.tensor; op.in2 = vb.tensor;
+            op.H = op.Ho = ta.H; op.W = op.Wo = ta.W; op.Cin = op.Cout = ta.C;
+            op.out = new_tensor(n->out, ta.H, ta.W, ta.C);
+            Val v; v.tensor = op.out; vals[n->out] = v;
+            P.ops.push_back(std::move(op));
+        } else if (n->op == "Resize" || n->op == "Upsample") {
+            if (!resize_is_up2(*n)) fail("Resize: only x2 nearest supported");
+            const Val& vi = need4d(n->in[0]);
+            const PTensor ti = P.tensors[vi.tensor];
+            POp op; op.kind = OpKind::UPSAMPLE; op.name = n->out; op.in = vi.tensor;
+            op.H = ti.H; op.W = ti.W; op.Ho = 2 * ti.H; op.Wo = 2 * ti.W; op.Cin = op.Cout = ti.C;
+            op.out = new_tensor(n->out, op.Ho, op.Wo, ti.C);
+            Val v; v.tensor = op.out; vals[n->out] = v;
+            P.ops.push_back(std::move(op));
+        } else if (n->op == "Transpose") {
+            const Val& vi = need4d(n->in[0]);
+            auto perm = n->src->attr_ints("perm");
+            if (perm != std::vector<int64_t>{0, 2, 3, 1}) fail("Transpose: only perm (0,2,3,1) supported");
+            Val v = vi; v.kind = Val::NHWC4D;
+            vals[n->out] = v;
+        } else if (n->op == "Flatten") {
+            auto it = vals.find(n->in[0]);
+            if (it == vals.end()) fail("Flatten input undefined");
+            Val v = it->second;
+            if (n->src->attr_i("axis", 1) != 1) fail("Flatten: only axis=1 supported");
+            if (v.kind == Val::NCHW4D) v.kind = Val::FLAT_NCHW;
+            else if (v.kind == Val::NHWC4D) { v.kind = Val::FLAT_STORAGE; v.rows = 1; v.cols = (int)P.tensors[v.tensor].elems(); }
+            vals[n->out] = v;
+        } else if (n->op == "Reshape") {
+            auto it = vals.find(n->in[0]);
+            if (it == vals.end()) fail("Reshape input undefined");
+            Val v = it->second;
+            const auto& shp = init_of(m, n->src->inputs.at(1)).i;
+            if (shp.empty()) fail("Reshape: empty target shape");
+            const PTensor& t = P.tensors[v.tensor];
+            const int64_t last = shp.back();
+            if (last <= 0 || t.elems() % (size_t)last) fail("Reshape: last dimension must be a positive divisor of the tensor size");
+            const bool storage_order = v.kind == Val::NHWC4D || v.kind == Val::FLAT_STORAGE ||
+                                       (v.kind == Val::NCHW4D && (t.H * t.W == 1 || t.C == 1)) ||
+                                       (v.kind == Val::FLAT_NCHW && (t.H * t.W == 1 || t.C == 1));
+            if (!storage_order) fail("Reshape of an NCHW-ordered value would need a physical transpose (not supported)");
+            v.kind = Val::FLAT_STORAGE; v.cols = (int)last; v.rows = (int)(t.elems() / (size_t)last);
+            vals[n->out] = v;
+        } else {
+            fail("internal: unhandled op " + n->op);
+        }
+    }
+
+    // ---------------------------------------------------------------- 8. outputs
+    for (const auto& o : m.outputs) {
+        auto it = vals.find(o.name);
+        if (it == vals.end()) fail("graph output '" + o.name + "' was never produced");
+        const Val& v = it->second;
+        const PTensor& t = P.tensors[v.tensor];
+        OutDesc d; d.name = o.name; d.tensor = v.tensor;
+        if (v.kind == Val::FLAT_STORAGE) { d.rows = v.rows; d.cols = v.cols; }
+        else if (v.kind == Val::NHWC4D) { d.rows = t.H * t.W; d.cols = t.C; }
+        else if (t.H * t.W == 1) { d.rows = 1; d.cols = t.C; }
+        else fail("graph output '" + o.name + "' is NCHW-ordered; only channels-last / flattened outputs are supported");
+        P.tensors[v.tensor].is_output = true;
+        P.outputs.push_back(d);
+    }
+
+    // ---------------------------------------------------------------- 9. liveness + arena
+    for (size_t i = 0; i < P.ops.size(); ++i) {
+        const POp& op = P.ops[i];
+        for (int t : {op.in, op.in2, op.res, op.out, op.out2}) {
+            if (t < 0) continue;
+            PTensor& pt = P.tensors[t];
+            if (pt.first < 0) pt.first = (int)i;
+            pt.last = (int)i;
+        }
+    }
+    const int nops = (int)P.ops.size();
+    for (auto& t : P.tensors) {
+        if (t.is_input) t.first = 0;
+        if (t.is_input || t.is_output) t.last = nops;       // keep for the caller
+        if (t.first < 0) { t.first = 0; t.last = 0; }
+    }
+    {
+        // greedy first-fit on (lifetime, size); offsets aligned to 64 floats (256 B)
+        std::vector<int> order(P.tensors.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return P.tensors[a].elems() > P.tensors[b].elems(); });
+        std::vector<int> placed;
+        for (int id : order) {
+            PTensor& t = P.tensors[id];
+            const size_t sz = (t.elems() + 63) / 64 * 64;
+            std::vector<std::pair<size_t, size_t>> busy;
+            for (int q : placed) {
+                const PTensor& o = P.tensors[q];
+                if (o.last < t.first || t.last < o.first) continue;
+                busy.push_back({o.offset, o.offset + (o.elems() + 63) / 64 * 64});
+            }
+            std::sort(busy.begin(), busy.end());
+            size_t off = 0;
+            for (auto& b : busy) { if (off + sz <= b.first) break; off = std::max(off, b.second); }
+            t.offset = off;
+            P.arena_elems = std::max(P.arena_elems, off + sz);
+            placed.push_back(id);
+        }
+    }
+    // ---------------------------------------------------------------- 10. accounting
+    for (auto& op : P.ops) {
+        double b = 0;
+        for (int t : {op.in, op.in2, op.res, op.out, op.out2}) if (t >= 0) b += (double)P.tensors[t].elems() * 4;
+        op.bytes = b;
+        P.macs += op.macs;
+        P.act_bytes += b;
+        P.weight_bytes += (double)(op.weight.size() + op.bias.size() + op.slope.size() + op.s2.size() + op.t2.size()) * 4;
+    }
+    return P;
+}
+
+std::string Plan::describe() const {
+    static const char* kinds[] = {"CONV", "DWCONV", "GEMM", "AFFINE", "ACT", "ADD", "UPSAMPLE"};
+    static const char* acts[] = {"", "+relu", "+prelu", "+sigmoid"};
+    std::ostringstream os;
+    os << "input " << inH << "x" << inW << "  ops " << ops.size() << "  tensors " << tensors.size()
+       << "  GMAC/image " << macs * 1e-9 << "  act MB/image " << act_bytes * 1e-6
+       << "  weights MB " << weight_bytes * 1e-6 << "  arena MB/image " << arena_elems * 4e-6 << "\n";
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const POp& o = ops[i];
+        os << i << " " << kinds[(int)o.kind] << " k" << o.ks << "s" << o.stride << " " << o.H << "x" << o.W << "x" << o.Cin
+           << " -> " << o.Ho << "x" << o.Wo << "x" << o.Cout << acts[(int)o.act];
+        if (o.res >= 0) os << (o.res_mode == ResMode::UP2X ? " +res(up2x)" : " +res");
+        if (o.out2 >= 0) os << (o.out >= 0 ? " +bn2nd" : " bn2nd-only");
+        os << "  MMAC " << o.macs * 1e-6 << "\n";
+    }
+    for (auto& d : outputs) os << "out " << d.name << " [" << d.rows << "x" << d.cols << "]\n";
+    return os.str();
+}
+
+}  // namespace fh

@@ -1,0 +1,68 @@
+// plan.h — ONNX graph → fused channels-last (NHWC) execution plan for the closed op set of the
+// two face graphs (SCRFD det_500m, ArcFace IResNet): Conv (dense / depthwise), BatchNormalization,
+// PRelu, Relu, Sigmoid, Add, Resize(nearest x2), Transpose(0,2,3,1), Reshape, Flatten, Gemm.
+//
+// This is host-only code (no HIP): it replaces ONNX Runtime's graph optimiser
+// (ORT_ENABLE_ALL, reference src/face_detector.cpp:11) for this path.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "onnx_reader.h"
+
+namespace fh {
+
+enum class Act : int { NONE = 0, RELU = 1, PRELU = 2, SIGMOID = 3 };
+enum class ResMode : int { NONE = 0, SAME = 1, UP2X = 2 };
+enum class OpKind : int { CONV = 0, DWCONV = 1, GEMM = 2, AFFINE = 3, ACT = 4, ADD = 5, UPSAMPLE = 6 };
+
+struct PTensor {
+    std::string name;
+    int H = 1, W = 1, C = 1;          // stored NHWC extent per image (graph input C=3 is stored as 4)
+    size_t elems() const { return (size_t)H * W * C; }
+    size_t offset = 0;                // per-image float offset inside the activation arena
+    int first = -1, last = -1;        // op index range in which the tensor is live
+    bool is_input = false, is_output = false;
+};
+
+struct POp {
+    OpKind kind = OpKind::CONV;
+    std::string name;
+    int in = -1, in2 = -1;            // in2: second operand of a standalone ADD
+    int out = -1, out2 = -1, res = -1;
+    ResMode res_mode = ResMode::NONE;
+    Act act = Act::NONE;
+    int ks = 1, stride = 1, pad = 0;
+    int Cin = 0, Cout = 0, H = 0, W = 0, Ho = 0, Wo = 0;
+    // Parameters (host fp32):
+    //  CONV  : weight[Cout][ks*ks][Cin]   (k = tap*Cin + ci, Cin = stored channels of `in`)
+    //  DWCONV: weight[9][C]
+    //  GEMM  : weight[N][K], K re-ordered to the NHWC flatten of the producer
+    //  AFFINE: s2/t2 applied to `in`
+    std::vector<float> weight, bias, slope, s2, t2;
+    double macs = 0;                  // multiply-accumulates per image
+    double bytes = 0;                 // algorithmic activation bytes per image (in + res + outs)
+};
+
+struct OutDesc {
+    std::string name;
+    int tensor = -1;
+    int rows = 0, cols = 0;           // per-image view: rows x cols floats, contiguous
+};
+
+struct Plan {
+    std::vector<PTensor> tensors;
+    std::vector<POp> ops;
+    int input = -1;
+    int inH = 0, inW = 0, inC = 3;
+    std::vector<OutDesc> outputs;     // in graph output order
+    size_t arena_elems = 0;           // per image
+    double macs = 0, act_bytes = 0, weight_bytes = 0;
+    std::string describe() const;     // human-readable op list (tests + DESIGN.md tables)
+};
+
+// inH/inW: the spatial size to plan for — the model's static shape if it has one, else the
+// reference's defaults 640 / 112 (src/face_detector.cpp:39-57).
+Plan build_plan(const OnnxModel& m, int inH, int inW);
+
+}  // namespace fh

@@ -1,0 +1,137 @@
+/* facehip.h — C ABI of libfacehip.so: the MI355X (gfx950) implementation of the
+ * detect -> align -> embed -> compare path of cucibala/FaceRecognizeOnnx.
+ *
+ * This is the drop-in boundary: every entry point names the reference interface it replaces
+ * (paths relative to the reference root).  Plain pointers and sizes only; no C++ or torch types.
+ * Host-pointer entry points reproduce the reference's batch-1 class API; the *_dev entry
+ * points take device pointers (HBM-resident inputs/outputs) and a hipStream_t passed as
+ * void*, and are asynchronous on that stream unless stated otherwise.
+ *
+ * Error convention: functions returning int give >= 0 on success and a negative fh_status on
+ * failure; fh_last_error() holds the message of the calling thread's last failure.  Nothing
+ * throws across this boundary.  Handles own all device memory; one handle = one device
+ * (the device current when it was created) and calls on one handle must not overlap.
+ */
+#ifndef FACEHIP_H_
+#define FACEHIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FH_API __attribute__((visibility("default")))
+
+enum fh_status { FH_OK = 0, FH_ERR_ARG = -1, FH_ERR_MODEL = -2, FH_ERR_DEVICE = -3, FH_ERR_STATE = -4 };
+
+/* POD mirror of `struct FaceBox` (src/face_detector.h:8-12): cv::Rect box, float score,
+ * cv::Point2f landmarks[5] (left eye, right eye, nose, left mouth, right mouth).  60 bytes. */
+typedef struct fh_face {
+    int32_t x, y, w, h;
+    float score;
+    float lm[10];
+} fh_face;
+
+typedef struct fh_det fh_det;         /* FaceDetector   (src/face_detector.h:14-43)   */
+typedef struct fh_rec fh_rec;         /* FaceRecognizer (src/face_recognizer.h:9-38)  */
+typedef struct fh_gallery fh_gallery; /* 1:N extension of compareFaces                */
+
+FH_API const char* fh_version(void);
+FH_API const char* fh_last_error(void);
+/* Selects the HIP device for subsequently created handles; returns the device count or < 0. */
+FH_API int fh_init(int device);
+
+/* ---- host-only introspection (no GPU needed): parse + plan an .onnx, write a text summary. */
+FH_API int fh_plan_describe(const char* onnx_path, int default_h, int default_w, char* buf, int cap);
+
+/* ---- FaceDetector ------------------------------------------------------------------------
+ * fh_det_create   <- FaceDetector::FaceDetector + loadModel   (src/face_detector.cpp:5-12,20-90)
+ *                    NULL on failure (the reference returns false).
+ * fh_det_detect   <- FaceDetector::detect                    (src/face_detector.cpp:139-222)
+ *                    host BGR u8 image (cv::Mat data/rows/cols/step); returns the number of
+ *                    faces written to out (score-descending, <= max_out); 0 for the
+ *                    reference's empty-result cases (null/empty image, bad size, unexpected
+ *                    output layout).                                                        */
+FH_API fh_det* fh_det_create(const char* onnx_path);
+FH_API void fh_det_destroy(fh_det* d);
+FH_API int fh_det_input_size(const fh_det* d, int* width, int* height);
+FH_API int fh_det_num_anchors(const fh_det* d);
+FH_API double fh_det_macs_per_frame(const fh_det* d);
+FH_API double fh_det_act_bytes_per_frame(const fh_det* d);
+FH_API int fh_det_detect(fh_det* d, const uint8_t* bgr, int rows, int cols, int step, float score_thr, float nms_thr,
+                         fh_face* out, int max_out);
+/* n frames of identical size resident in HBM.  d_out: [n][max_per_frame] fh_face, d_counts: [n]
+ * (total survivors per frame; entries beyond max_per_frame are not stored). */
+FH_API int fh_det_detect_batch_dev(fh_det* d, const uint8_t* d_frames, int n, int rows, int cols, int step,
+                                   long long frame_stride, float score_thr, float nms_thr, fh_face* d_out,
+                                   int max_per_frame, int* d_counts, void* stream);
+/* Stage hooks for parity tests: run preprocess + network only / read a raw network output
+ * (device pointer to [n][rows][cols] fp32, valid until the next call on the handle). */
+FH_API int fh_det_run_network_dev(fh_det* d, const uint8_t* d_frames, int n, int rows, int cols, int step,
+                                  long long frame_stride, void* stream);
+FH_API int fh_det_num_outputs(const fh_det* d);
+FH_API const float* fh_det_output_dev(fh_det* d, int index, int* rows, int* cols);
+FH_API const float* fh_det_input_dev(fh_det* d);          /* preprocessed input, NHWC with 4 lanes */
+FH_API int fh_det_postprocess_dev(fh_det* d, int n, float score_thr, float nms_thr, fh_face* d_out, int max_per_frame,
+                                  int* d_counts, void* stream);
+
+/* ---- FaceRecognizer ----------------------------------------------------------------------
+ * fh_rec_create          <- FaceRecognizer ctor + loadModel (src/face_recognizer.cpp:5-13,21-91)
+ * fh_rec_extract         <- extractFeature(image, face)     (src/face_recognizer.cpp:236-304)
+ * fh_rec_extract_simple  <- extractFeatureSimple(image)     (src/face_recognizer.cpp:152-234)
+ *                           return the feature length written to out (L2-normalised), 0 for the
+ *                           reference's empty-vector cases, < 0 on error.
+ * fh_compare             <- compareFaces(f1, f2)            (src/face_recognizer.cpp:320-334)  */
+FH_API fh_rec* fh_rec_create(const char* onnx_path);
+FH_API void fh_rec_destroy(fh_rec* r);
+FH_API int fh_rec_input_size(const fh_rec* r, int* width, int* height);
+FH_API int fh_rec_feature_dim(const fh_rec* r);
+FH_API double fh_rec_macs_per_face(const fh_rec* r);
+FH_API double fh_rec_act_bytes_per_face(const fh_rec* r);
+FH_API int fh_rec_set_chunk(fh_rec* r, int faces_per_pass);
+FH_API int fh_rec_extract(fh_rec* r, const uint8_t* bgr, int rows, int cols, int step, const fh_face* face, float* out,
+                          int out_cap);
+FH_API int fh_rec_extract_simple(fh_rec* r, const uint8_t* bgr, int rows, int cols, int step, float* out, int out_cap);
+FH_API float fh_compare(const float* f1, int n1, const float* f2, int n2);
+/* n pre-aligned crops [n][H][W][3] BGR u8 in HBM -> d_out [n][dim] L2-normalised; d_raw (may be
+ * NULL) receives the un-normalised network output. */
+FH_API int fh_rec_embed_aligned_dev(fh_rec* r, const uint8_t* d_crops, int n, float* d_out, float* d_raw, void* stream);
+/* alignFace for n faces (d_frame_of[i] = frame index of face i, NULL = identity): writes crops
+ * [n][H][W][3] and d_ok[n] (1 warped, 2 crop-resize fallback, 0 empty). */
+FH_API int fh_rec_align_dev(fh_rec* r, const uint8_t* d_frames, int rows, int cols, int step, long long frame_stride,
+                            const fh_face* d_faces, const int* d_frame_of, int n, uint8_t* d_crops, int* d_ok,
+                            void* stream);
+FH_API int fh_rec_embed_faces_dev(fh_rec* r, const uint8_t* d_frames, int rows, int cols, int step,
+                                  long long frame_stride, const fh_face* d_faces, const int* d_frame_of, int n,
+                                  float* d_out, int* d_ok, void* stream);
+
+/* ---- detect -> align -> embed on a batch of HBM-resident frames (the headline metric path).
+ * Takes the first min(count, faces_per_frame) faces of each frame (score order).  d_faces /
+ * d_frame_of / d_emb must hold n*faces_per_frame entries; the compacted face list is written
+ * front-to-back.  Returns the number of faces embedded (synchronises the stream once to learn
+ * it) or < 0. */
+FH_API int fh_pipeline_run_dev(fh_det* d, fh_rec* r, const uint8_t* d_frames, int n, int rows, int cols, int step,
+                               long long frame_stride, float score_thr, float nms_thr, int faces_per_frame,
+                               fh_face* d_faces, int* d_frame_of, float* d_emb, void* stream);
+
+/* ---- gallery (1:N compareFaces): rows are L2-normalised features; scores are (dot+1)/2. */
+FH_API fh_gallery* fh_gallery_create(int dim);
+FH_API void fh_gallery_destroy(fh_gallery* g);
+FH_API int fh_gallery_upload(fh_gallery* g, const float* rows, long long n, int rows_on_device, long long index_base);
+FH_API int fh_gallery_topk_dev(fh_gallery* g, const float* d_queries, int nq, int k, float* d_scores, int* d_indices,
+                               void* stream);
+
+/* ---- single kernels exposed for parity tests and micro-benchmarks (device pointers). */
+FH_API int fh_resize_u8c3_dev(const uint8_t* d_src, int sh, int sw, int sstep, uint8_t* d_dst, int dh, int dw, int dstep,
+                              void* stream);
+FH_API int fh_conv_forward_dev(const float* d_in, const float* d_wt_packed, const float* d_bias, float* d_out, int batch,
+                               int h, int w, int cin, int cout, int ksize, int stride, int kpad, int cfg, void* stream);
+FH_API int fh_conv_wt_rows(int cout);
+FH_API int fh_conv_kpad(int ktot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FACEHIP_H_ */

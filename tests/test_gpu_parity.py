@@ -1,0 +1,342 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Bars: integer / byte / index work bit-exact; fp32 network outputs within the
+tolerances written next to each assert; embeddings within 1e-3 cosine of the oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import facerecognizeonnx_amd as fa            # noqa: E402
+from facerecognizeonnx_amd import _lib        # noqa: E402
+from oracle import oracle                     # noqa: E402
+from tests import util                        # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a real device: the product path has no CPU fallback")
+    fa.lib().fh_init(0)
+    oracle.set_threads(8)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def pack_weights(w):
+    """ONNX [Cout,Cin,k,k] -> packed [rows][Kpad] with k = tap*Cin + ci (kernels.h ConvArgs.wt)."""
+    cout, cin, k, _ = w.shape
+    L = fa.lib()
+    rows, kpad = L.fh_conv_wt_rows(cout), L.fh_conv_kpad(k * k * cin)
+    out = np.zeros((rows, kpad), np.float32)
+    out[:cout, :k * k * cin] = w.transpose(0, 2, 3, 1).reshape(cout, k * k * cin)
+    return out, kpad
+
+
+CONV_CASES = [
+    # B, H,  W,  Cin, Cout, k, stride, cfg
+    (2, 14, 14, 64, 128, 3, 1, 0),
+    (1, 9, 11, 32, 96, 3, 2, 0),
+    (3, 7, 7, 64, 64, 3, 1, 3),
+    (1, 28, 28, 64, 64, 3, 2, 1),
+    (2, 12, 10, 16, 16, 3, 1, 2),
+    (1, 20, 20, 40, 72, 1, 1, 2),
+    (1, 13, 13, 4, 24, 3, 2, 2),
+    (2, 8, 8, 152, 288, 1, 1, -1),
+    (1, 10, 10, 72, 40, 1, 2, -1),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,cfg", CONV_CASES)
+def test_conv_layer_matches_oracle(B, H, W, Cin, Cout, k, stride, cfg):
+    rng = np.random.default_rng(B * 1000 + H * 10 + Cin)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = oracle.conv2d(x, w, b, stride, k // 2, 1)                       # NCHW
+    wp, kpad = pack_weights(w)
+    xd, wd, bd = dev(x.transpose(0, 2, 3, 1)), dev(wp), dev(b)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    out = torch.full((B, Ho, Wo, Cout), float("nan"), device="cuda")
+    rc = fa.lib().fh_conv_forward_dev(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout,
+                                      k, stride, kpad, cfg, 0)
+    assert rc == 0, _lib.last_error()
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().transpose(0, 3, 1, 2)
+    # fp32 sums of <= 2.6k products of O(1) values: 2e-5 absolute covers the order-of-summation difference
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+
+
+def test_det_preprocess_bit_exact(models_dir):
+    det = fa.FaceDetector()
+    assert det.loadModel(util.tiny_scrfd(models_dir, hw=128))
+    for rows, cols in ((128, 128), (96, 128), (200, 150), (64, 50)):
+        img = util.frames_u8(1, rows, cols, seed=rows, smooth=True)[0]
+        ref, scale = oracle.det_preprocess(img, 128, 128)
+        d = dev(img)
+        rc = fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), 1, rows, cols, cols * 3, rows * cols * 3, 0)
+        assert rc == 1, _lib.last_error()
+        torch.cuda.synchronize()
+        p = fa.lib().fh_det_input_dev(det.handle)
+        t = torch.empty((128, 128, 4), device="cuda")
+        _copy_from_dev(t, p, t.numel() * 4)
+        got = t.cpu().numpy()
+        assert np.array_equal(got[..., :3].transpose(2, 0, 1), ref), (rows, cols)
+        assert np.all(got[..., 3] == 0)
+
+
+def _copy_from_dev(dst_tensor, src_ptr, nbytes):
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rc = hip.hipMemcpy(dst_tensor.data_ptr(), src_ptr, nbytes, 3)        # hipMemcpyDeviceToDevice
+    assert rc == 0
+    torch.cuda.synchronize()
+
+
+def _det_outputs(det, n):
+    outs = []
+    for i in range(fa.lib().fh_det_num_outputs(det.handle)):
+        r, c = C.c_int(), C.c_int()
+        p = fa.lib().fh_det_output_dev(det.handle, i, C.byref(r), C.byref(c))
+        t = torch.empty((n, r.value, c.value), device="cuda")
+        _copy_from_dev(t, p, t.numel() * 4)
+        outs.append(t.cpu().numpy())
+    return outs
+
+
+def test_scrfd_network_and_postprocess(models_dir):
+    path = util.tiny_scrfd(models_dir, hw=None, cls_bias=-0.5)            # dynamic H/W -> 640 default
+    det = fa.FaceDetector()
+    assert det.loadModel(path)
+    assert det.input_size() == (640, 640) and det.num_anchors() == 16800
+    odet = oracle.OracleDetector()
+    assert odet.loadModel(path)
+    n = 2
+    frames = util.frames_u8(n, 640, 640, seed=5, smooth=True)
+    d = dev(frames)
+    assert fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), n, 640, 640, 640 * 3, 640 * 640 * 3, 0) == n
+    torch.cuda.synchronize()
+    got = _det_outputs(det, n)
+    for b in range(n):
+        inp, scale = oracle.det_preprocess(frames[b], 640, 640)
+        ref = odet.run_network(inp)
+        for i in range(9):
+            # fp32 network, 40 layers, activations O(1..10): 1e-4 absolute
+            np.testing.assert_allclose(got[i][b], ref[i], rtol=1e-4, atol=1e-4, err_msg=f"output {i}")
+    # decode + threshold + NMS must be BIT-exact given the same network outputs
+    max_pf = 512
+    faces = torch.zeros((n, max_pf, 15), dtype=torch.float32, device="cuda")          # 60-byte records
+    counts = torch.zeros(n, dtype=torch.int32, device="cuda")
+    for thr, nms in ((0.5, 0.4), (0.3, 0.2), (0.6, 0.7)):
+        assert fa.lib().fh_det_postprocess_dev(det.handle, n, thr, nms, faces.data_ptr(), max_pf, counts.data_ptr(), 0) == n
+        torch.cuda.synchronize()
+        cnt = counts.cpu().numpy()
+        rec = faces.cpu().numpy().view(np.uint8).reshape(n, max_pf, 60).copy().view(fa.FACE_DTYPE).reshape(n, max_pf)
+        for b in range(n):
+            rows = oracle.scrfd_decode([g[b] for g in got], 640, 640)
+            ref = oracle.postprocess_rows(rows, 1.0, thr, nms)
+            assert cnt[b] == len(ref) and len(ref) > 0, (thr, nms, cnt[b], len(ref))
+            k = min(len(ref), max_pf)
+            assert rec[b, :k].tobytes() == ref[:k].tobytes(), (thr, nms, b)
+
+
+def test_detect_host_api_matches_oracle_end_to_end(models_dir):
+    path = util.tiny_scrfd(models_dir, hw=128, cls_bias=-0.5)
+    det = fa.FaceDetector(); odet = oracle.OracleDetector()
+    assert det.loadModel(path) and odet.loadModel(path)
+    for rows, cols in ((128, 128), (100, 180), (300, 200)):
+        img = util.frames_u8(1, rows, cols, seed=cols, smooth=True)[0]
+        got = det.detect_records(img, 0.5, 0.4)
+        ref = odet.detect(img, 0.5, 0.4)
+        # network outputs differ by ~1e-6, so a score within that distance of the threshold or a
+        # coordinate within that distance of an integer may flip: compare with +-1 px / 1e-4 slack
+        assert abs(len(got) - len(ref)) <= max(2, len(ref) // 50), (len(got), len(ref))
+        m = min(len(got), len(ref), 5)
+        for a, b in zip(got[:m], ref[:m]):
+            assert abs(a["score"] - b["score"]) < 1e-4
+            assert max(abs(int(a[k]) - int(b[k])) for k in ("x", "y", "w", "h")) <= 1
+            np.testing.assert_allclose(a["lm"], b["lm"], atol=1e-2)
+    assert len(det.detect_records(None)) == 0
+    assert len(det.detect_records(np.zeros((0, 0, 3), np.uint8))) == 0
+
+
+def test_predecoded_layout_bit_exact(models_dir):
+    from facerecognizeonnx_amd.synth import models
+    for three_d in (True, False):
+        path = models.make_predecoded_det(os.path.join(models_dir, f"pre{int(three_d)}.onnx"), 64, 7, three_d)
+        det = fa.FaceDetector(); odet = oracle.OracleDetector()
+        assert det.loadModel(path) and odet.loadModel(path)
+        img = util.frames_u8(1, 64, 64, seed=9)[0]
+        d = dev(img[None])
+        assert fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), 1, 64, 64, 192, 64 * 192, 0) == 1
+        torch.cuda.synchronize()
+        rows = _det_outputs(det, 1)[0][0]
+        faces = torch.zeros((1, 64, 15), device="cuda"); counts = torch.zeros(1, dtype=torch.int32, device="cuda")
+        assert fa.lib().fh_det_postprocess_dev(det.handle, 1, 0.5, 0.4, faces.data_ptr(), 64, counts.data_ptr(), 0) == 1
+        torch.cuda.synchronize()
+        ref = oracle.postprocess_rows(rows, 1.0, 0.5, 0.4)
+        assert int(counts[0]) == len(ref) and len(ref) > 0
+        rec = faces.cpu().numpy().view(np.uint8).reshape(64, 60).copy().view(fa.FACE_DTYPE).reshape(64)
+        assert rec[:len(ref)].tobytes() == ref.tobytes()
+
+
+def _align_gpu(rec, frames, faces, frame_of=None):
+    n = len(faces)
+    fd, facd = dev(frames), dev(faces.view(np.uint8).reshape(n, 60))
+    crops = torch.zeros((n, 112, 112, 3), dtype=torch.uint8, device="cuda")
+    ok = torch.zeros(n, dtype=torch.int32, device="cuda")
+    fo = dev(np.asarray(frame_of, np.int32)) if frame_of is not None else None
+    rows, cols = frames.shape[1:3]
+    rc = fa.lib().fh_rec_align_dev(rec.handle, fd.data_ptr(), rows, cols, cols * 3, rows * cols * 3, facd.data_ptr(),
+                                   fo.data_ptr() if fo is not None else 0, n, crops.data_ptr(), ok.data_ptr(), 0)
+    assert rc == n, _lib.last_error()
+    torch.cuda.synchronize()
+    return crops.cpu().numpy(), ok.cpu().numpy()
+
+
+def test_align_bit_exact(models_dir):
+    rec = fa.FaceRecognizer()
+    assert rec.loadModel(util.tiny_iresnet(models_dir))
+    nfr, n = 3, 48
+    frames = util.frames_u8(nfr, 240, 320, seed=11, smooth=True)
+    lms = util.random_landmarks(n, 240, 320, seed=3)
+    rng = np.random.default_rng(4)
+    lms[5] = rng.uniform(0, 240, (5, 2))                # garbage landmarks: RANSAC drops points
+    lms[6] = lms[6][0]                                   # all coincident -> no transform -> crop fallback
+    lms[7] = lms[7][0]
+    lms[8] += 400                                        # far outside the frame: all taps read the border
+    faces = np.zeros(n, fa.FACE_DTYPE)
+    faces["lm"] = lms.reshape(n, 10)
+    faces["x"], faces["y"], faces["w"], faces["h"] = 30, 40, 90, 100
+    faces[7]["x"] = 1000                                 # fallback with an empty intersection -> empty result
+    frame_of = rng.integers(0, nfr, n)
+    crops, ok = _align_gpu(rec, frames, faces, frame_of)
+    for i in range(n):
+        ref = oracle.align_face(frames[frame_of[i]], faces[i])
+        if ref is None:
+            assert ok[i] == 0, i
+        else:
+            assert ok[i] in (1, 2), i
+            assert np.array_equal(crops[i], ref), f"face {i}: {np.abs(crops[i].astype(int) - ref).max()}"
+    assert ok[6] == 2 and ok[7] == 0 and ok[0] == 1
+
+
+def test_resize_bit_exact():
+    rng = np.random.default_rng(0)
+    for (sh, sw, dh, dw) in ((480, 640, 112, 112), (100, 100, 50, 50), (37, 53, 112, 112), (640, 360, 640, 360),
+                             (123, 77, 61, 200), (64, 64, 128, 128)):
+        img = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        ref = oracle.resize_bilinear(img, dw, dh)
+        s, d = dev(img), torch.zeros((dh, dw, 3), dtype=torch.uint8, device="cuda")
+        assert fa.lib().fh_resize_u8c3_dev(s.data_ptr(), sh, sw, sw * 3, d.data_ptr(), dh, dw, dw * 3, 0) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(d.cpu().numpy(), ref), (sh, sw, dh, dw)
+
+
+@pytest.mark.parametrize("fold_bn", [True, False])
+def test_tiny_iresnet_embeddings(models_dir, fold_bn):
+    path = util.tiny_iresnet(models_dir, fold_bn=fold_bn)
+    rec = fa.FaceRecognizer(); orec = oracle.OracleRecognizer()
+    assert rec.loadModel(path) and orec.loadModel(path)
+    assert rec.feature_dim() == 512
+    n = 5
+    crops = util.frames_u8(n, 112, 112, seed=2)
+    cd = dev(crops)
+    out = torch.zeros((n, 512), device="cuda"); raw = torch.zeros((n, 512), device="cuda")
+    assert rec.embed_aligned_dev(cd.data_ptr(), n, out.data_ptr(), raw.data_ptr()) == n
+    torch.cuda.synchronize()
+    got, graw = out.cpu().numpy(), raw.cpu().numpy()
+    for i in range(n):
+        inp = oracle.rec_preprocess(crops[i])
+        r = oracle.run_graph(orec.g, {orec.g.inputs[0][0]: inp[None]})[orec.g.outputs[0][0]].reshape(-1)
+        np.testing.assert_allclose(graw[i], r, rtol=1e-4, atol=1e-4)
+        ref = oracle.l2_normalize(r)
+        assert 1.0 - float(np.dot(got[i], ref)) < 1e-5            # north-star bar is 1e-3
+        np.testing.assert_allclose(got[i], ref, atol=1e-5)
+        assert abs(np.linalg.norm(got[i]) - 1.0) < 1e-5
+
+
+def test_extract_feature_host_api(models_dir):
+    path = util.tiny_iresnet(models_dir)
+    rec = fa.FaceRecognizer(); orec = oracle.OracleRecognizer()
+    assert rec.loadModel(path) and orec.loadModel(path)
+    img = util.frames_u8(1, 200, 260, seed=21, smooth=True)[0]
+    face = np.zeros(1, fa.FACE_DTYPE)
+    face["lm"] = util.random_landmarks(1, 200, 260, seed=8).reshape(1, 10)
+    face["x"], face["y"], face["w"], face["h"] = 20, 30, 100, 120
+    f1 = rec.extractFeature(img, face[0]); r1 = orec.extractFeature(img, face[0])
+    assert f1.shape == (512,) and 1.0 - float(np.dot(f1, r1)) < 1e-5
+    f2 = rec.extractFeatureSimple(img); r2 = orec.extractFeatureSimple(img)
+    assert 1.0 - float(np.dot(f2, r2)) < 1e-5
+    assert abs(rec.compareFaces(f1, f2) - oracle.compare(r1, r2)) < 1e-5
+    assert rec.compareFaces(f1, f1[:100]) == 0.0
+    assert rec.extractFeature(None, face[0]).size == 0
+    bad = face.copy(); bad["lm"] = 5.0; bad["x"] = 5000                   # no transform, empty crop
+    assert rec.extractFeature(img, bad[0]).size == 0
+
+
+def test_full_size_r50_cosine(models_dir):
+    """IResNet-50 (6.31 GMAC/face): embeddings within 1e-3 cosine of the oracle (north-star bar)."""
+    from facerecognizeonnx_amd.synth import models
+    path = models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
+    rec = fa.FaceRecognizer(); orec = oracle.OracleRecognizer()
+    assert rec.loadModel(path) and orec.loadModel(path)
+    assert abs(rec.macs_per_face() - 6.309e9) < 5e6
+    n = 3
+    crops = util.frames_u8(n, 112, 112, seed=2, smooth=True)
+    cd = dev(crops); out = torch.zeros((n, 512), device="cuda")
+    assert rec.embed_aligned_dev(cd.data_ptr(), n, out.data_ptr()) == n
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i in range(2):
+        ref = orec.embed_aligned(crops[i])
+        cos = float(np.dot(got[i], ref))
+        assert 1.0 - cos < 1e-3, cos
+        assert np.abs(got[i] - ref).max() < 1e-4
+    # batch independence: same crop in a different batch slot gives the same embedding
+    cd2 = dev(crops[::-1].copy()); out2 = torch.zeros((n, 512), device="cuda")
+    rec.embed_aligned_dev(cd2.data_ptr(), n, out2.data_ptr()); torch.cuda.synchronize()
+    np.testing.assert_allclose(out2.cpu().numpy()[::-1], got, atol=1e-6)
+
+
+def test_pipeline_and_gallery(models_dir):
+    dpath = util.tiny_scrfd(models_dir, hw=128, cls_bias=-0.5)
+    rpath = util.tiny_iresnet(models_dir)
+    det = fa.FaceDetector(); rec = fa.FaceRecognizer()
+    assert det.loadModel(dpath) and rec.loadModel(rpath)
+    odet = oracle.OracleDetector(); orec = oracle.OracleRecognizer()
+    assert odet.loadModel(dpath) and orec.loadModel(rpath)
+    n, F = 6, 2
+    frames = util.frames_u8(n, 128, 128, seed=31, smooth=True)
+    fd = dev(frames)
+    faces = torch.zeros((n * F, 15), device="cuda"); fo = torch.zeros(n * F, dtype=torch.int32, device="cuda")
+    emb = torch.zeros((n * F, 512), device="cuda")
+    total = fa.pipeline_run_dev(det, rec, fd.data_ptr(), n, 128, 128, F, faces.data_ptr(), fo.data_ptr(), emb.data_ptr())
+    torch.cuda.synchronize()
+    assert 0 < total <= n * F
+    recs = faces.cpu().numpy().view(np.uint8).reshape(n * F, 60).copy().view(fa.FACE_DTYPE).reshape(n * F)[:total]
+    frame_of = fo.cpu().numpy()[:total]; e = emb.cpu().numpy()[:total]
+    assert np.all(np.diff(frame_of) >= 0)
+    for i in range(total):
+        ref = orec.extractFeature(frames[frame_of[i]], recs[i])         # oracle on the GPU's own boxes
+        assert ref.size == 512 and 1.0 - float(np.dot(e[i], ref)) < 1e-5
+    # gallery top-k vs oracle (scores (dot+1)/2, order score desc / index asc)
+    rng = np.random.default_rng(4)
+    G, k = 5000, 5
+    gal = rng.standard_normal((G, 512)).astype(np.float32); gal /= np.linalg.norm(gal, axis=1, keepdims=True)
+    gal[123] = e[0]; gal[4000] = e[0]                                     # exact duplicates: tie broken by index
+    g = fa.Gallery(512); gd = dev(gal); g.upload(gd.data_ptr(), G, True)
+    sc = torch.zeros((total, k), device="cuda"); ix = torch.zeros((total, k), dtype=torch.int32, device="cuda")
+    g.topk_dev(emb.data_ptr(), total, k, sc.data_ptr(), ix.data_ptr()); torch.cuda.synchronize()
+    rs, ri = oracle.gallery_topk(e, gal, k)
+    assert np.array_equal(ix.cpu().numpy(), ri)
+    np.testing.assert_allclose(sc.cpu().numpy(), rs, atol=2e-6)
+    assert list(ri[0][:2]) == [123, 4000]
