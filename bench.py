@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — faces/sec of the end-to-end detect -> align -> embed path on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (N>1: launched through
+torch.distributed.run, one rank per GPU) prints ONE JSON line on rank 0.
+
+* workload (BASELINE.json `metric`): a batch of 128 synthetic 640x640 BGR frames resident in HBM,
+  SCRFD det_500m (synthetic weights) -> anchor decode -> NMS -> first F faces per frame ->
+  5-point alignment to 112x112 -> ArcFace IResNet-50 (synthetic weights) -> L2-normalise.
+  value = faces embedded per second, whole job (all ranks).  One step = one batch.
+* multi-GPU: frames are sharded one batch per rank (weak scaling); the headline path has no
+  exchange step, so no collective is on the data path — only the timing barrier / max-reduce.
+* roofline: the dominant kernel is the f32-MFMA implicit-GEMM convolution; its launches are
+  bracketed by HIP events inside the library during the timed region (fh_timing_*), achieved =
+  algorithmic FLOP of those launches / their summed duration, peak = 157.3 TFLOP/s (f32 MFMA).
+* cpu_baseline: the CPU oracle (oracle/, a restatement — NOT ONNX Runtime) timed on a bounded
+  sample on the host cores with the reference's 4 threads (src/face_detector.cpp:10).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+CFG_NAMES = ["conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<256,64,4,1>", "conv_igemm_kernel<128,32,4,1>",
+             "conv_igemm_kernel<64,64,2,2>", "dwconv3x3_kernel", "other graph ops"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=128, help="frames per batch per GPU")
+    ap.add_argument("--faces-per-frame", type=int, default=1)
+    ap.add_argument("--workload", default="e2e", choices=["e2e", "embed", "detect"])
+    ap.add_argument("--crops", type=int, default=256, help="--workload embed: pre-aligned crops per batch (config 2)")
+    ap.add_argument("--score-thr", type=float, default=0.5)
+    ap.add_argument("--nms-thr", type=float, default=0.4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(det_path, rec_path, frames_np, args):
+    """Oracle (CPU restatement) on a bounded sample, 4 threads like the reference."""
+    from oracle import oracle
+    threads = min(4, os.cpu_count() or 1)
+    oracle.set_threads(threads)
+    od, orc = oracle.OracleDetector(), oracle.OracleRecognizer()
+    assert od.loadModel(det_path) and orc.loadModel(rec_path)
+    n = max(1, min(args.cpu_sample_frames, len(frames_np)))
+    t0 = time.perf_counter()
+    faces = 0
+    for i in range(n):
+        if args.workload == "embed":
+            orc.embed_aligned(frames_np[i])
+            faces += 1
+            continue
+        det = od.detect(frames_np[i], args.score_thr, args.nms_thr)
+        if args.workload == "detect":
+            faces += 1
+            continue
+        for f in det[:args.faces_per_frame]:
+            if orc.extractFeature(frames_np[i], f).size:
+                faces += 1
+    dt = time.perf_counter() - t0
+    unit = "frames/s" if args.workload == "detect" else "faces/s"
+    what = {"e2e": f"{n} of the batch's 640x640 frames: detect + decode + NMS + align + embed of the first "
+                   f"{args.faces_per_frame} face(s) per frame",
+            "embed": f"{n} of the batch's 112x112 crops: preprocess + IResNet-50 + L2-normalise",
+            "detect": f"{n} of the batch's 640x640 frames: SCRFD + decode + NMS"}[args.workload]
+    return {"value": faces / dt, "unit": unit, "cores": threads, "kind": "port",
+            "sample": what + f" ({dt:.1f} s, CPU oracle = restatement of the reference, not ONNX Runtime)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import facerecognizeonnx_amd as fa
+    from facerecognizeonnx_amd.synth import models
+    L = fa.lib()
+    fa._lib.check(L.fh_init(local), "fh_init")
+
+    # synthetic models (seeded; the genuine .onnx files are not available offline)
+    if local == 0:
+        det_path = models.cached("det_500m_seed100.onnx", models.make_det_500m)
+        rec_path = models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
+    if dist is not None:
+        dist.barrier()
+    det_path = models.cached("det_500m_seed100.onnx", models.make_det_500m)
+    rec_path = models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
+    det, rec = fa.FaceDetector(), fa.FaceRecognizer()
+    if not det.loadModel(det_path) or not rec.loadModel(rec_path):
+        raise SystemExit("model load failed: " + fa._lib.last_error())
+
+    B, F = args.frames, args.faces_per_frame
+    rng = np.random.default_rng(rank)
+    stream = torch.cuda.current_stream().cuda_stream
+    if args.workload == "embed":
+        nunits = args.crops
+        host = rng.integers(0, 256, (nunits, 112, 112, 3), dtype=np.uint8)
+        data = torch.from_numpy(host).cuda()
+        emb = torch.zeros((nunits, 512), device="cuda")
+
+        def step():
+            rec.embed_aligned_dev(data.data_ptr(), nunits, emb.data_ptr(), 0, stream)
+            return nunits
+    else:
+        host = rng.integers(0, 256, (B, 640, 640, 3), dtype=np.uint8)
+        data = torch.from_numpy(host).cuda()
+        faces = torch.zeros((B * F, 15), device="cuda")
+        frame_of = torch.zeros(B * F, dtype=torch.int32, device="cuda")
+        emb = torch.zeros((B * F, 512), device="cuda")
+        counts = torch.zeros(B, dtype=torch.int32, device="cuda")
+        if args.workload == "detect":
+            def step():
+                det.detect_batch_dev(data.data_ptr(), B, 640, 640, faces.data_ptr(), F, counts.data_ptr(),
+                                     args.score_thr, args.nms_thr, stream=stream)
+                return B
+        else:
+            def step():
+                return fa.pipeline_run_dev(det, rec, data.data_ptr(), B, 640, 640, F, faces.data_ptr(), frame_of.data_ptr(),
+                                           emb.data_ptr(), args.score_thr, args.nms_thr, stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    timing = not args.no_kernel_timing
+    if timing:
+        L.fh_timing_enable(1)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    units = 0
+    for _ in range(args.steps):
+        units += step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ms, fl, by = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_double * 6)()
+    ln = (C.c_longlong * 6)()
+    if timing:
+        L.fh_timing_enable(0)
+        fa._lib.check(L.fh_timing_collect(ms, fl, by, ln, 6), "fh_timing_collect")
+
+    total_units, max_dt = float(units), dt
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        u = torch.tensor([float(units)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        max_dt, total_units = float(t.item()), float(u.item())
+
+    if rank == 0:
+        per_step_faces = units / max(args.steps, 1)
+        out = {
+            "metric": "faces/sec end-to-end (detect+align+embed), batch=128 640x640" if args.workload == "e2e" else
+                      ("faces/sec ArcFace w600k_r50 embed, pre-aligned crops" if args.workload == "embed" else
+                       "frames/sec SCRFD det_500m detect+decode+NMS"),
+            "value": total_units / max_dt,
+            "unit": "frames/s" if args.workload == "detect" else "faces/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * max_dt / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": {"e2e": f"C-headline: {B} frames 640x640 per GPU, SCRFD det_500m + decode + NMS, first {F} "
+                                           f"face(s)/frame aligned to 112x112, IResNet-50 (w600k_r50) embed, L2-norm",
+                                    "embed": f"C2: {args.crops} pre-aligned 112x112 crops per GPU, IResNet-50 (w600k_r50), fp32",
+                                    "detect": f"C3: {B} frames 640x640 per GPU, SCRFD det_500m + decode + NMS"}[args.workload],
+                       "frames_per_gpu": B, "faces_per_frame": F, "faces_per_step_rank0": per_step_faces,
+                       "score_thr": args.score_thr, "nms_thr": args.nms_thr,
+                       "weights": "synthetic seeded (det seed 100, rec seed 200)",
+                       "parallelism": f"frame-sharded x{world}, no data-path collective"},
+        }
+        if timing:
+            conv = [(ms[i], fl[i], ln[i], i) for i in range(4) if ln[i] > 0]
+            if conv:
+                dom = max(conv)
+                tf = dom[1] / (dom[0] * 1e-3) / 1e12
+                allms, allfl = sum(c[0] for c in conv), sum(c[1] for c in conv)
+                out["roofline"] = {"bound": "mfma", "kernel": CFG_NAMES[dom[3]], "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "launches": int(dom[2]), "avg_launch_us": 1e3 * dom[0] / dom[2],
+                                   "algorithmic_gflop_per_launch": dom[1] / dom[2] / 1e9,
+                                   "all_conv_igemm": {"achieved": allfl / (allms * 1e-3) / 1e12,
+                                                      "frac": allfl / (allms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
+                                                      "ms_per_step": allms / args.steps},
+                                   "per_kernel_ms_per_step": {CFG_NAMES[i]: ms[i] / args.steps for i in range(6) if ln[i] > 0}}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(det_path, rec_path, host, args)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,11 @@ PROTOTYPES = {
     "fh_gallery_destroy": (None, [_vp]),
     "fh_gallery_upload": (_i, [_vp, _vp, _ll, _i, _ll]),
     "fh_gallery_topk_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "fh_timing_enable": (_i, [_i]),
+    "fh_timing_collect": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "fh_det_set_conv_cfg": (_i, [_vp, _i]),
+    "fh_rec_set_conv_cfg": (_i, [_vp, _i]),
+    "fh_memcpy_d2h": (_i, [_vp, _vp, C.c_size_t]),
     "fh_resize_u8c3_dev": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "fh_conv_forward_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fh_conv_wt_rows": (_i, [_i]),
@@ -87,6 +92,13 @@ def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
         path = build()
+        # PyTorch (device memory / streams / torch.distributed plumbing) bundles its own HIP
+        # runtime.  It has to be loaded FIRST so that libfacehip.so binds to the same runtime
+        # instance; two runtimes in one process do not share a device context.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol

@@ -63,9 +63,9 @@ class FaceDetector:
         self.close()
 
     def close(self):
-        if getattr(self, "_h", None):
-            _lib.lib().fh_det_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None and getattr(_lib, "_LIB", None) is not None:
+            _lib._LIB.fh_det_destroy(self._h)
+        self._h = None
 
     # -- reference API ---------------------------------------------------------------------
     def loadModel(self, modelPath: str) -> bool:                      # face_detector.cpp:20-90
@@ -122,9 +122,9 @@ class FaceRecognizer:
         self.close()
 
     def close(self):
-        if getattr(self, "_h", None):
-            _lib.lib().fh_rec_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None and getattr(_lib, "_LIB", None) is not None:
+            _lib._LIB.fh_rec_destroy(self._h)
+        self._h = None
 
     # -- reference API ---------------------------------------------------------------------
     def loadModel(self, modelPath: str) -> bool:                      # face_recognizer.cpp:21-91
@@ -200,9 +200,9 @@ class Gallery:
         self.dim = dim
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            _lib.lib().fh_gallery_destroy(self._h)
-            self._h = None
+        if getattr(self, "_h", None) and _lib is not None and getattr(_lib, "_LIB", None) is not None:
+            _lib._LIB.fh_gallery_destroy(self._h)
+        self._h = None
 
     def upload(self, rows_ptr: int, n: int, on_device: bool, index_base: int = 0):
         check(_lib.lib().fh_gallery_upload(self._h, rows_ptr, n, int(on_device), index_base), "fh_gallery_upload")

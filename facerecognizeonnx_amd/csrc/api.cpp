@@ -275,7 +275,20 @@ int fh_gallery_topk_dev(fh_gallery* g, const float* q, int nq, int k, float* sco
     return guarded([&] { g->g.topk_dev(q, nq, k, scores, indices, S(stream)); return nq; });
 }
 
+// ---------------------------------------------------------------------------------- timing / tuning
+int fh_timing_enable(int on) { fh::KernelTimer::get().enabled = on != 0; return FH_OK; }
+int fh_timing_collect(double* ms, double* flops, double* bytes, long long* launches, int n) {
+    if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need 6-entry arrays");
+    return guarded([&] { fh::KernelTimer::get().collect(ms, flops, bytes, launches); return fh::KernelTimer::kTags; });
+}
+int fh_det_set_conv_cfg(fh_det* d, int cfg) { if (!d) return arg_error("null handle"); d->det.net().force_cfg = cfg; return FH_OK; }
+int fh_rec_set_conv_cfg(fh_rec* r, int cfg) { if (!r) return arg_error("null handle"); r->rec.net().force_cfg = cfg; return FH_OK; }
+
 // ---------------------------------------------------------------------------------- single kernels
+int fh_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    if (!dst || !src) return arg_error("fh_memcpy_d2h: null argument");
+    return guarded([&] { FH_HIP(hipDeviceSynchronize()); FH_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return 0; });
+}
 int fh_resize_u8c3_dev(const uint8_t* src, int sh, int sw, int sstep, uint8_t* dst, int dh, int dw, int dstep, void* stream) {
     if (!src || !dst || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0) return arg_error("fh_resize_u8c3_dev: bad argument");
     return guarded([&] {

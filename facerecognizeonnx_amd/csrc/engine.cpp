@@ -21,6 +21,36 @@ void DevBuf::ensure(size_t n) {
     bytes = n;
 }
 
+// ------------------------------------------------------------------------------------------ KernelTimer
+KernelTimer& KernelTimer::get() { static KernelTimer t; return t; }
+hipEvent_t KernelTimer::take() {
+    if (!pool_.empty()) { hipEvent_t e = pool_.back(); pool_.pop_back(); return e; }
+    hipEvent_t e; FH_HIP(hipEventCreate(&e)); return e;
+}
+void KernelTimer::begin(hipStream_t s) {
+    if (!enabled) return;
+    cur_ = take();
+    FH_HIP(hipEventRecord(cur_, s));
+}
+void KernelTimer::end(hipStream_t s, int tag, double flops, double bytes) {
+    if (!enabled || !cur_) return;
+    hipEvent_t b = take();
+    FH_HIP(hipEventRecord(b, s));
+    recs_.push_back(Rec{cur_, b, tag, flops, bytes});
+    cur_ = nullptr;
+}
+void KernelTimer::collect(double* ms, double* flops, double* bytes, long long* launches) {
+    for (int i = 0; i < kTags; ++i) { ms[i] = 0; flops[i] = 0; bytes[i] = 0; launches[i] = 0; }
+    for (auto& r : recs_) {
+        FH_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        FH_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        ms[r.tag] += t; flops[r.tag] += r.flops; bytes[r.tag] += r.bytes; launches[r.tag] += 1;
+        pool_.push_back(r.a); pool_.push_back(r.b);
+    }
+    recs_.clear();
+}
+
 // ------------------------------------------------------------------------------------------ Net
 static constexpr size_t kPartialFloats = (size_t)2 * 512 * 128 * 128;
 
@@ -90,9 +120,12 @@ void Net::run(int batch, hipStream_t s) {
     if (batch <= 0) return;
     if (batch > cap_) throw std::runtime_error("Net::run: batch exceeds reserved capacity");
     const float* P = params_.as<float>();
+    KernelTimer& timer = KernelTimer::get();
     for (size_t i = 0; i < plan_.ops.size(); ++i) {
         const POp& op = plan_.ops[i];
         const DevOp& d = dev_[i];
+        int tag = 5;
+        timer.begin(s);
         switch (op.kind) {
             case OpKind::CONV:
             case OpKind::GEMM: {
@@ -115,11 +148,13 @@ void Net::run(int batch, hipStream_t s) {
                 if (force_cfg < 0 && cfg == 0 && ((M + 127) / 128) * ((op.Cout + 127) / 128) < 256) cfg = 3;   // few tiles: go finer
                 a.nsplit = pick_split(op, batch, cfg);
                 launch_conv(a, cfg, s);
+                tag = cfg;
                 break;
             }
             case OpKind::DWCONV:
                 launch_dwconv3x3(tensor_ptr(op.in), P + d.wt, P + d.bias, tensor_ptr(op.out), batch, op.H, op.W, op.Cin, op.stride,
                                  (int)op.act, s);
+                tag = 4;
                 break;
             case OpKind::AFFINE:
                 launch_affine(tensor_ptr(op.in), P + d.s2, P + d.t2, tensor_ptr(op.out), (long)batch * op.H * op.W, op.Cin, s);
@@ -135,6 +170,7 @@ void Net::run(int batch, hipStream_t s) {
                 launch_upsample2x(tensor_ptr(op.in), tensor_ptr(op.out), batch, op.H, op.W, op.Cin, s);
                 break;
         }
+        timer.end(s, tag, 2.0 * op.macs * batch, op.bytes * batch);
     }
     FH_HIP(hipGetLastError());
 }

@@ -140,11 +140,11 @@ def make_w600k_r50(path: str, seed: int = 200) -> str:
 def make_scrfd(path: str, stage_blocks: Sequence[int] = (2, 3, 2, 6),
                stage_planes: Sequence[int] = (16, 16, 40, 72, 152, 288),
                neck_ch: int = 16, head_ch: int = 64, seed: int = 100,
-               cls_bias: float = -4.0, static_hw: int | None = None) -> str:
+               cls_bias: float = -3.0, static_hw: int | None = None, cls_gain: float = 20.0) -> str:
     """scrfd_500m_bnkps topology; BN folded as in the public export.
 
-    ``cls_bias`` shifts the score logits so that only a realistic fraction of the 16 800
-    anchors clears the 0.5 threshold on random frames; bbox distances are biased positive
+    ``cls_gain`` / ``cls_bias`` give score logits ~ N(cls_bias, 1) on random frames so that only a
+    realistic fraction (~0.1 %) of the 16 800 anchors clears the 0.5 threshold; bbox distances are biased positive
     so decoded boxes are proper rectangles and NMS has real overlaps to resolve.
     """
     W = _W(seed)
@@ -200,7 +200,7 @@ def make_scrfd(path: str, stage_blocks: Sequence[int] = (2, 3, 2, 6),
             h = conv(h, c, c, 3, 1, f"head.{stride}.cls_convs.{j}.dw", True, group=c)
             h = conv(h, c, head_ch, 1, 1, f"head.{stride}.cls_convs.{j}.pw", True)
             c = head_ch
-        cls = conv(h, c, 2 * 1, 3, 1, f"head.{stride}.cls", False, gain=0.5, bias_mean=cls_bias, bias_std=0.0)
+        cls = conv(h, c, 2 * 1, 3, 1, f"head.{stride}.cls", False, gain=cls_gain, bias_mean=cls_bias, bias_std=0.0)
         cls = b.node("Sigmoid", [cls])
         box = conv(h, c, 2 * 4, 3, 1, f"head.{stride}.reg", False, gain=0.5, bias_mean=2.0, bias_std=0.3)
         kps = conv(h, c, 2 * 10, 3, 1, f"head.{stride}.kps", False, gain=0.5, bias_mean=0.0, bias_std=0.5)
@@ -216,8 +216,8 @@ def make_scrfd(path: str, stage_blocks: Sequence[int] = (2, 3, 2, 6),
     return b.save(path)
 
 
-def make_det_500m(path: str, seed: int = 100, cls_bias: float = -4.0) -> str:
-    return make_scrfd(path, seed=seed, cls_bias=cls_bias)
+def make_det_500m(path: str, seed: int = 100, cls_bias: float = -3.0, cls_gain: float = 20.0) -> str:
+    return make_scrfd(path, seed=seed, cls_bias=cls_bias, cls_gain=cls_gain)
 
 
 # ----------------------------------------------------------------------------- pre-decoded detector

@@ -123,7 +123,18 @@ FH_API int fh_gallery_upload(fh_gallery* g, const float* rows, long long n, int 
 FH_API int fh_gallery_topk_dev(fh_gallery* g, const float* d_queries, int nq, int k, float* d_scores, int* d_indices,
                                void* stream);
 
+/* ---- measurement hooks (bench.py): per-launch HIP-event timing of the network kernels.
+ * Tags 0..3 = conv_igemm tile configs (128x128, 256x64, 128x32, 64x64), 4 = depthwise conv,
+ * 5 = other graph ops.  fh_timing_collect synchronises, fills 6-entry arrays (elapsed ms,
+ * algorithmic FLOP, algorithmic activation bytes, launches) and resets the counters.
+ * fh_*_set_conv_cfg forces one tile config for every dense conv of a handle (-1 = automatic). */
+FH_API int fh_timing_enable(int on);
+FH_API int fh_timing_collect(double* ms, double* flops, double* bytes, long long* launches, int n);
+FH_API int fh_det_set_conv_cfg(fh_det* d, int cfg);
+FH_API int fh_rec_set_conv_cfg(fh_rec* r, int cfg);
+
 /* ---- single kernels exposed for parity tests and micro-benchmarks (device pointers). */
+FH_API int fh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);   /* synchronous */
 FH_API int fh_resize_u8c3_dev(const uint8_t* d_src, int sh, int sw, int sstep, uint8_t* d_dst, int dh, int dw, int dstep,
                               void* stream);
 FH_API int fh_conv_forward_dev(const float* d_in, const float* d_wt_packed, const float* d_bias, float* d_out, int batch,

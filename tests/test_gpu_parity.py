@@ -86,19 +86,15 @@ def test_det_preprocess_bit_exact(models_dir):
         assert rc == 1, _lib.last_error()
         torch.cuda.synchronize()
         p = fa.lib().fh_det_input_dev(det.handle)
-        t = torch.empty((128, 128, 4), device="cuda")
-        _copy_from_dev(t, p, t.numel() * 4)
-        got = t.cpu().numpy()
+        got = _read_dev(p, (128, 128, 4))
         assert np.array_equal(got[..., :3].transpose(2, 0, 1), ref), (rows, cols)
         assert np.all(got[..., 3] == 0)
 
 
-def _copy_from_dev(dst_tensor, src_ptr, nbytes):
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    rc = hip.hipMemcpy(dst_tensor.data_ptr(), src_ptr, nbytes, 3)        # hipMemcpyDeviceToDevice
-    assert rc == 0
-    torch.cuda.synchronize()
+def _read_dev(ptr, shape):
+    out = np.empty(shape, np.float32)
+    assert fa.lib().fh_memcpy_d2h(out.ctypes.data, ptr, out.nbytes) == 0, _lib.last_error()
+    return out
 
 
 def _det_outputs(det, n):
@@ -106,14 +102,12 @@ def _det_outputs(det, n):
     for i in range(fa.lib().fh_det_num_outputs(det.handle)):
         r, c = C.c_int(), C.c_int()
         p = fa.lib().fh_det_output_dev(det.handle, i, C.byref(r), C.byref(c))
-        t = torch.empty((n, r.value, c.value), device="cuda")
-        _copy_from_dev(t, p, t.numel() * 4)
-        outs.append(t.cpu().numpy())
+        outs.append(_read_dev(p, (n, r.value, c.value)))
     return outs
 
 
 def test_scrfd_network_and_postprocess(models_dir):
-    path = util.tiny_scrfd(models_dir, hw=None, cls_bias=-0.5)            # dynamic H/W -> 640 default
+    path = util.tiny_scrfd(models_dir, hw=None, cls_bias=-2.0)            # dynamic H/W -> 640 default
     det = fa.FaceDetector()
     assert det.loadModel(path)
     assert det.input_size() == (640, 640) and det.num_anchors() == 16800
@@ -135,7 +129,7 @@ def test_scrfd_network_and_postprocess(models_dir):
     max_pf = 512
     faces = torch.zeros((n, max_pf, 15), dtype=torch.float32, device="cuda")          # 60-byte records
     counts = torch.zeros(n, dtype=torch.int32, device="cuda")
-    for thr, nms in ((0.5, 0.4), (0.3, 0.2), (0.6, 0.7)):
+    for thr, nms in ((0.5, 0.4), (0.3, 0.2), (0.45, 0.7), (0.9, 0.4)):
         assert fa.lib().fh_det_postprocess_dev(det.handle, n, thr, nms, faces.data_ptr(), max_pf, counts.data_ptr(), 0) == n
         torch.cuda.synchronize()
         cnt = counts.cpu().numpy()
@@ -143,19 +137,20 @@ def test_scrfd_network_and_postprocess(models_dir):
         for b in range(n):
             rows = oracle.scrfd_decode([g[b] for g in got], 640, 640)
             ref = oracle.postprocess_rows(rows, 1.0, thr, nms)
-            assert cnt[b] == len(ref) and len(ref) > 0, (thr, nms, cnt[b], len(ref))
+            assert cnt[b] == len(ref) and (len(ref) > 0 or thr > 0.5), (thr, nms, cnt[b], len(ref))
             k = min(len(ref), max_pf)
             assert rec[b, :k].tobytes() == ref[:k].tobytes(), (thr, nms, b)
 
 
 def test_detect_host_api_matches_oracle_end_to_end(models_dir):
-    path = util.tiny_scrfd(models_dir, hw=128, cls_bias=-0.5)
+    path = util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0)
     det = fa.FaceDetector(); odet = oracle.OracleDetector()
     assert det.loadModel(path) and odet.loadModel(path)
     for rows, cols in ((128, 128), (100, 180), (300, 200)):
         img = util.frames_u8(1, rows, cols, seed=cols, smooth=True)[0]
         got = det.detect_records(img, 0.5, 0.4)
         ref = odet.detect(img, 0.5, 0.4)
+        assert len(ref) > 0
         # network outputs differ by ~1e-6, so a score within that distance of the threshold or a
         # coordinate within that distance of an integer may flip: compare with +-1 px / 1e-4 slack
         assert abs(len(got) - len(ref)) <= max(2, len(ref) // 50), (len(got), len(ref))
@@ -308,7 +303,7 @@ def test_full_size_r50_cosine(models_dir):
 
 
 def test_pipeline_and_gallery(models_dir):
-    dpath = util.tiny_scrfd(models_dir, hw=128, cls_bias=-0.5)
+    dpath = util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0)
     rpath = util.tiny_iresnet(models_dir)
     det = fa.FaceDetector(); rec = fa.FaceRecognizer()
     assert det.loadModel(dpath) and rec.loadModel(rpath)

@@ -15,7 +15,7 @@ def tiny_iresnet(d, fold_bn=True, seed=1):
                                112, 512, seed=seed, fold_bn=fold_bn)
 
 
-def tiny_scrfd(d, hw=None, seed=2, cls_bias=-1.0):
+def tiny_scrfd(d, hw=None, seed=2, cls_bias=-2.0):
     return models.make_scrfd(os.path.join(d, f"s_tiny_{hw}_{seed}.onnx"), (1, 2, 1, 2), (8, 8, 16, 24, 32, 48), 8, 16,
                              seed=seed, cls_bias=cls_bias, static_hw=hw)
 
