@@ -76,8 +76,9 @@ PROTOTYPES = {
     "fh_gallery_topk_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "fh_timing_enable": (_i, [_i]),
     "fh_timing_collect": (_i, [_vp, _vp, _vp, _vp, _i]),
-    "fh_det_set_conv_cfg": (_i, [_vp, _i]),
-    "fh_rec_set_conv_cfg": (_i, [_vp, _i]),
+    "fh_timing_collect_ops": (_i, [_vp, _vp, _vp, _i]),
+    "fh_det_set_conv_cfg": (_i, [_vp, _i, _i]),
+    "fh_rec_set_conv_cfg": (_i, [_vp, _i, _i]),
     "fh_memcpy_d2h": (_i, [_vp, _vp, C.c_size_t]),
     "fh_resize_u8c3_dev": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "fh_conv_forward_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),

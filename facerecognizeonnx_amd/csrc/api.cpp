@@ -281,8 +281,20 @@ int fh_timing_collect(double* ms, double* flops, double* bytes, long long* launc
     if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need 6-entry arrays");
     return guarded([&] { fh::KernelTimer::get().collect(ms, flops, bytes, launches); return fh::KernelTimer::kTags; });
 }
-int fh_det_set_conv_cfg(fh_det* d, int cfg) { if (!d) return arg_error("null handle"); d->det.net().force_cfg = cfg; return FH_OK; }
-int fh_rec_set_conv_cfg(fh_rec* r, int cfg) { if (!r) return arg_error("null handle"); r->rec.net().force_cfg = cfg; return FH_OK; }
+int fh_timing_collect_ops(double* ms, double* flops, int* tag, int cap) {
+    if (!ms || !flops || !tag || cap <= 0) return arg_error("fh_timing_collect_ops: bad argument");
+    return guarded([&] { return fh::KernelTimer::get().collect_ops(ms, flops, tag, cap); });
+}
+int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k) {
+    if (!d) return arg_error("null handle");
+    d->det.net().force_cfg = cfg; d->det.net().sk_enable = stream_k != 0;
+    return FH_OK;
+}
+int fh_rec_set_conv_cfg(fh_rec* r, int cfg, int stream_k) {
+    if (!r) return arg_error("null handle");
+    r->rec.net().force_cfg = cfg; r->rec.net().sk_enable = stream_k != 0;
+    return FH_OK;
+}
 
 // ---------------------------------------------------------------------------------- single kernels
 int fh_memcpy_d2h(void* dst, const void* src, size_t bytes) {
@@ -308,7 +320,10 @@ int fh_conv_forward_dev(const float* in, const float* wt, const float* bias, flo
         a.in = in; a.wt = wt; a.bias = bias; a.out1 = out;
         a.B = batch; a.H = h; a.W = w; a.Cin = cin; a.Cout = cout; a.ks = ks; a.stride = stride; a.pad = pad;
         a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1;
-        a.Kpad = kpad; a.nsplit = 1;
+        a.Kpad = kpad;
+        static fh::DevBuf slabs;                 // test entry point only: one shared workspace
+        slabs.ensure(fh::conv_slab_floats() * sizeof(float));
+        a.slabs = slabs.as<float>(); a.sk_enable = 1;
         fh::launch_conv(a, cfg, S(stream));
         FH_HIP(hipGetLastError());
         return 0;

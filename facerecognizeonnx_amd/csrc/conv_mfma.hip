@@ -9,16 +9,29 @@
 // Activations are channels-last, so a K-chunk of 32 consecutive k is 128 contiguous bytes of
 // one input pixel: every global load is a full 16-byte lane access and 8 lanes cover one line.
 //
-// Tile anatomy (256 threads = 4 waves, 2 workgroups per CU):
-//   * global -> registers -> LDS, double buffered; one barrier per 32-deep K chunk.
+// Tile anatomy (256 threads = 4 waves, >= 2 workgroups per CU):
+//   * global -> registers -> LDS, double buffered; one barrier per 32-deep K chunk.  Padding,
+//     ragged M and ragged K are resolved by redirecting the lane's load to a zero line (no
+//     branches in the loader).
 //   * LDS image [row][32 k] with the 16-byte column XOR-swizzled by (row>>1)&7, which makes the
 //     ds_read_b128 fragment reads of 32 different rows conflict-free (MI355X_MICROARCH.md §LDS).
 //   * each lane fetches 4 consecutive k of its row with ONE ds_read_b128 and feeds 4 MFMAs; the
-//     k-order inside a chunk is therefore permuted identically for A and B, which a dot product
-//     does not care about.  A wave tile of 64x64 needs 4 ds_read_b128 per 16 MFMAs.
-//   * zero padding, ragged M and ragged K are resolved in the loader (masked loads of 0).
+//     k-order inside a chunk is therefore permuted identically for both operands, which a dot
+//     product does not care about.  A wave tile of 64x64 needs 4 ds_read_b128 per 16 MFMAs;
+//     the fragments of the next 8-deep step are fetched while the current 16 MFMAs issue.
+//   * the MFMA's A operand is the WEIGHT fragment and B the PIXEL fragment, so a lane ends up
+//     with one pixel and, per accumulator quad, 4 consecutive output channels: the epilogue
+//     moves float4s (residual in, output out, second output out).
 //   * epilogue: bias -> activation -> (+ residual, optionally through a 2x nearest up-sampling)
 //     -> store, plus an optional second output  y*s2 + t2  (the next block's pre-conv BN).
+//
+// Work distribution ("stream-K remainder"): with T tiles and S workgroups resident on the chip,
+// the first floor(T/S)*S tiles are computed one per workgroup; the K-chunks of the remaining
+// R < S tiles are dealt out evenly over up to S further workgroups of the same launch, each
+// covering a contiguous run of chunks (at most two tile segments).  Segments store their raw
+// accumulators to slabs; a small fix-up kernel sums a tile's slabs in K order and runs the same
+// epilogue.  Deterministic (no atomics), no inter-workgroup hand-off inside a launch, and it
+// doubles as split-K for the 25088-deep FC and for small-batch late stages.
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -37,84 +50,261 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
 }
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvArgs p, const int tiles_n,
-                                                                     const int chunks_total,
-                                                                     const int chunks_per_split) {
-    constexpr int T = WM * WN * 64;
-    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int RP = T / 8;                    // tile rows filled per loader pass
-    constexpr int AL = BM / RP, BL = BN / RP;
+struct Tile {
+    static constexpr int T = WM * WN * 64;
+    static constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static constexpr int RP = T / 8;                    // tile rows filled per loader pass
+    static constexpr int AL = BM / RP, BL = BN / RP;
+    static constexpr int SLAB = BM * BN;                // floats per accumulator slab
     static_assert(TM >= 1 && TN >= 1 && AL >= 1 && BL >= 1 && RP % 16 == 0, "tile shape");
+};
+
+// ---- epilogue shared by the main kernel and the fix-up kernel -------------------------------
+// C/D map of the 32x32 MFMA: column (= pixel here) = lane & 31, row (= channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0,
+                                              int wm, int wn, int lane) {
+    using TL = Tile<BM, BN, WM, WN>;
+    const int fr = lane & 31, fh2 = lane >> 5;
+    const int HoWo = p.Ho * p.Wo;
+    const int M = p.B * HoWo;
+    const float* __restrict__ res = p.res;
+    float* __restrict__ out1 = p.out1;
+    float* __restrict__ out2 = p.out2;
+    const bool vec = (p.Cout & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < TL::TM; ++i) {
+        const int m = m0 + (wm * TL::TM + i) * 32 + fr;
+        if (m >= M) continue;
+        const size_t row = (size_t)m * p.Cout;
+        size_t rrow = row;
+        if (p.res_mode == (int)ResMode::UP2X) {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            rrow = ((size_t)(n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout;
+        }
+#pragma unroll
+        for (int j = 0; j < TL::TN; ++j) {
+            const int cb = n0 + (wn * TL::TN + j) * 32 + 4 * fh2;
+            if (vec) {
+                v4f r4[4];
+                if (p.res_mode != (int)ResMode::NONE) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = cb + 8 * g;
+                        r4[g] = co < p.Cout ? *reinterpret_cast<const v4f*>(res + rrow + co) : v4f{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = cb + 8 * g;
+                    if (co >= p.Cout) continue;
+                    const v4f b4 = p.bias ? *reinterpret_cast<const v4f*>(p.bias + co) : v4f{0.f, 0.f, 0.f, 0.f};
+                    v4f sl = {0.f, 0.f, 0.f, 0.f};
+                    if (p.act == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(p.slope + co);
+                    v4f v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = apply_act(acc[i][j][4 * g + c] + b4[c], p.act, sl[c]);
+                    if (p.res_mode != (int)ResMode::NONE) v += r4[g];
+                    if (out1) *reinterpret_cast<v4f*>(out1 + row + co) = v;
+                    if (out2) {
+                        const v4f s2 = *reinterpret_cast<const v4f*>(p.s2 + co), t2 = *reinterpret_cast<const v4f*>(p.t2 + co);
+                        *reinterpret_cast<v4f*>(out2 + row + co) = v * s2 + t2;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = cb + 8 * (e >> 2) + (e & 3);
+                    if (co >= p.Cout) continue;
+                    float v = apply_act(acc[i][j][e] + (p.bias ? p.bias[co] : 0.f), p.act, p.slope ? p.slope[co] : 0.f);
+                    if (p.res_mode != (int)ResMode::NONE) v += res[rrow + co];
+                    if (out1) out1[row + co] = v;
+                    if (out2) out2[row + co] = v * p.s2[co] + p.t2[co];
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvArgs p, const int tiles_n, const int chunks) {
+    using TL = Tile<BM, BN, WM, WN>;
+    constexpr int TM = TL::TM, TN = TL::TN, RP = TL::RP, AL = TL::AL, BL = TL::BL;
     __shared__ v4f lds[2][(BM + BN) * 8];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int tile_n = blockIdx.x % tiles_n, tile_m = blockIdx.x / tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HoWo = p.Ho * p.Wo;
     const int M = p.B * HoWo;
     const int Ktot = p.ks * p.ks * p.Cin;
-    const int c0 = blockIdx.y * chunks_per_split;
-    const int c1 = min(chunks_total, c0 + chunks_per_split);
-
-    // ---- loader bookkeeping: this thread fills 16-byte column `lq` of rows lrow + i*RP
+    const bool cin32 = (p.Cin & 31) == 0;
     const int lrow = tid >> 3, lq = tid & 7;
     const int sw = lq ^ ((lrow >> 1) & 7);
-    int a_base[AL];
-    unsigned a_mask[AL];
-#pragma unroll
-    for (int i = 0; i < AL; ++i) {
-        const int m = m0 + lrow + i * RP;
-        a_base[i] = 0; a_mask[i] = 0;
-        if (m < M) {
-            const int n = m / HoWo, rem = m - n * HoWo;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-            a_base[i] = ((n * p.H + iy0) * p.W + ix0) * p.Cin;
-            unsigned mk = 0;
-            for (int ky = 0; ky < p.ks; ++ky)
-                for (int kx = 0; kx < p.ks; ++kx)
-                    if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W)
-                        mk |= 1u << (ky * p.ks + kx);
-            a_mask[i] = mk;
-        }
-    }
-    const float* wrow[BL];
-#pragma unroll
-    for (int i = 0; i < BL; ++i) wrow[i] = p.wt + (size_t)(n0 + lrow + i * RP) * p.Kpad + lq * 4;
-    const bool cin32 = (p.Cin & 31) == 0;
+    const int fr = lane & 31, fh2 = lane >> 5;
+    const int fsw = (fr >> 1) & 7;
 
-    v4f ra[AL], rb[BL];
-    auto load_chunk = [&](int kc) {
-        const int kb = kc * 32;
-        int tap, ci;
-        if (cin32) {                              // whole chunk inside one tap (wave-uniform)
-            tap = kb / p.Cin;
-            ci = kb - tap * p.Cin + lq * 4;
-        } else {
-            const int k4 = kb + lq * 4;
-            tap = k4 / p.Cin;
-            ci = k4 - tap * p.Cin;
-        }
-        const bool kvalid = kb + lq * 4 < Ktot;
-        const int ky = tap / p.ks, kx = tap - ky * p.ks;
-        const int toff = (ky * p.W + kx) * p.Cin + ci;
+    // ---- which tile(s) and which K range: full tiles first, then stream-K segments
+    int tile, c_begin, c_end, nseg = 1, seg1_len = 0;
+    bool to_slab = false;
+    int sk_w = 0;
+    if ((int)blockIdx.x < p.sk_full) {
+        tile = blockIdx.x; c_begin = 0; c_end = chunks;
+    } else {
+        sk_w = blockIdx.x - p.sk_full;
+        const int u0 = sk_w * p.sk_q;
+        const int u1 = min(p.sk_units, u0 + p.sk_q);
+        tile = p.sk_full + u0 / chunks;
+        c_begin = u0 - (u0 / chunks) * chunks;
+        c_end = min(chunks, c_begin + (u1 - u0));
+        seg1_len = (u1 - u0) - (c_end - c_begin);
+        nseg = seg1_len > 0 ? 2 : 1;
+        to_slab = true;
+    }
+
+    for (int seg = 0; seg < nseg; ++seg) {
+        if (seg == 1) { tile += 1; c_begin = 0; c_end = seg1_len; }
+        const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+        // ---- loader bookkeeping: this thread fills 16-byte column `lq` of rows lrow + i*RP
+        int a_base[AL];
+        unsigned a_mask[AL];
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
-            v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (kvalid && ((a_mask[i] >> tap) & 1u)) v = *reinterpret_cast<const v4f*>(p.in + (long)(a_base[i] + toff));
-            ra[i] = v;
+            const int m = m0 + lrow + i * RP;
+            a_base[i] = 0; a_mask[i] = 0;
+            if (m < M) {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+                a_base[i] = ((n * p.H + iy0) * p.W + ix0) * p.Cin;
+                unsigned mk = 0;
+                if (p.ks == 3) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+                        if ((unsigned)(iy0 + t / 3) < (unsigned)p.H && (unsigned)(ix0 + t % 3) < (unsigned)p.W) mk |= 1u << t;
+                } else {
+                    mk = 1u;
+                }
+                a_mask[i] = mk;
+            }
         }
+        const float* wrow[BL];
 #pragma unroll
-        for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const v4f*>(wrow[i] + kb);
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < AL; ++i) lds[buf][(lrow + i * RP) * 8 + sw] = ra[i];
-#pragma unroll
-        for (int i = 0; i < BL; ++i) lds[buf][BM * 8 + (lrow + i * RP) * 8 + sw] = rb[i];
-    };
+        for (int i = 0; i < BL; ++i) wrow[i] = p.wt + (size_t)(n0 + lrow + i * RP) * p.Kpad + lq * 4;
 
+        v4f ra[AL], rb[BL];
+        auto load_chunk = [&](int kc) {
+            const int kb = kc * 32;
+            int tap, ci;
+            if (cin32) {                              // whole chunk inside one tap (wave-uniform)
+                tap = kb / p.Cin;
+                ci = kb - tap * p.Cin + lq * 4;
+            } else {
+                const int k4 = kb + lq * 4;
+                tap = k4 / p.Cin;
+                ci = k4 - tap * p.Cin;
+            }
+            const bool kvalid = kb + lq * 4 < Ktot;
+            int toff = ci;
+            if (p.ks == 3) { const int ky = tap / 3, kx = tap - ky * 3; toff += (ky * p.W + kx) * p.Cin; }
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                const float* src = (kvalid && ((a_mask[i] >> tap) & 1u)) ? p.in + (long)(a_base[i] + toff) : p.zeros;
+                ra[i] = *reinterpret_cast<const v4f*>(src);
+            }
+#pragma unroll
+            for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const v4f*>(wrow[i] + kb);
+        };
+        auto store_chunk = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < AL; ++i) lds[buf][(lrow + i * RP) * 8 + sw] = ra[i];
+#pragma unroll
+            for (int i = 0; i < BL; ++i) lds[buf][BM * 8 + (lrow + i * RP) * 8 + sw] = rb[i];
+        };
+
+        v16f acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        auto compute = [&](int buf) {
+            const v4f* X = lds[buf] + (wm * TM * 32 + fr) * 8;
+            const v4f* Wt = lds[buf] + BM * 8 + (wn * TN * 32 + fr) * 8;
+            v4f x[2][TM], w[2][TN];
+            {
+                const int col = fh2 ^ fsw;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) x[0][i] = X[i * 32 * 8 + col];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) w[0][j] = Wt[j * 32 * 8 + col];
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                if (s < 3) {
+                    const int col = (2 * (s + 1) + fh2) ^ fsw;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) x[nxt][i] = X[i * 32 * 8 + col];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) w[nxt][j] = Wt[j * 32 * 8 + col];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[cur][j][e], x[cur][i][e], acc[i][j], 0, 0, 0);
+            }
+        };
+
+        if (c_begin < c_end) {
+            load_chunk(c_begin);
+            store_chunk(0);
+            __syncthreads();
+            for (int kc = c_begin, it = 0; kc < c_end; ++kc, ++it) {
+                const int buf = it & 1;
+                const bool more = kc + 1 < c_end;
+                if (more) load_chunk(kc + 1);
+                compute(buf);
+                if (more) store_chunk(buf ^ 1);
+                __syncthreads();
+            }
+        }
+
+        if (!to_slab) {
+            conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+        } else {
+            float* __restrict__ slab = p.slabs + ((size_t)sk_w * 2 + seg) * TL::SLAB;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        v4f v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        *reinterpret_cast<v4f*>(slab + ((size_t)((i * TN + j) * 4 + g) * TL::T + tid) * 4) = v;
+                    }
+        }
+    }
+}
+
+// Sums the slabs of one stream-K tile in K order and applies the epilogue.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs p, const int tiles_n, const int chunks) {
+    using TL = Tile<BM, BN, WM, WN>;
+    constexpr int TM = TL::TM, TN = TL::TN;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    const int r = blockIdx.x;                           // remainder tile index
+    const int tile = p.sk_full + r;
+    const int ub = r * chunks, ue = ub + chunks;        // this tile's unit range
+    const int w_first = ub / p.sk_q, w_last = (ue - 1) / p.sk_q;
     v16f acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -122,105 +312,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int fr = lane & 31, fh2 = lane >> 5;
-    const int fsw = (fr >> 1) & 7;
-    auto compute = [&](int buf) {
-        const v4f* A = lds[buf] + (wm * TM * 32 + fr) * 8;
-        const v4f* Bt = lds[buf] + BM * 8 + (wn * TN * 32 + fr) * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int col = (2 * s + fh2) ^ fsw;
-            v4f a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = A[i * 32 * 8 + col];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bt[j * 32 * 8 + col];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    if (c0 < c1) {
-        load_chunk(c0);
-        store_chunk(0);
-        __syncthreads();
-        for (int kc = c0, it = 0; kc < c1; ++kc, ++it) {
-            const int buf = it & 1;
-            const bool more = kc + 1 < c1;
-            if (more) load_chunk(kc + 1);
-            compute(buf);
-            if (more) store_chunk(buf ^ 1);
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue.  C/D map of the 32x32 MFMA: column = lane & 31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = n0 + (wn * TN + j) * 32 + fr;
-        if (co >= p.Cout) continue;
-        if (p.nsplit > 1) {
-            float* slab = p.partial + (size_t)blockIdx.y * M * p.Cout;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh2;
-                    if (m < M) slab[(size_t)m * p.Cout + co] = acc[i][j][e];
-                }
-            continue;
-        }
-        const float bias = p.bias ? p.bias[co] : 0.f;
-        const float slope = p.slope ? p.slope[co] : 0.f;
-        const float s2 = p.out2 ? p.s2[co] : 0.f, t2 = p.out2 ? p.t2[co] : 0.f;
+    for (int w = w_first; w <= w_last; ++w) {
+        const int seg = (w * p.sk_q >= ub) ? 0 : 1;     // a workgroup's 2nd segment is the tile it spills into
+        const float* __restrict__ slab = p.slabs + ((size_t)w * 2 + seg) * TL::SLAB;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh2;
-                if (m >= M) continue;
-                float v = apply_act(acc[i][j][e] + bias, p.act, slope);
-                if (p.res_mode == (int)ResMode::SAME) {
-                    v += p.res[(size_t)m * p.Cout + co];
-                } else if (p.res_mode == (int)ResMode::UP2X) {
-                    const int n = m / HoWo, rem = m - n * HoWo;
-                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                    v += p.res[((size_t)(n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + co];
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const v4f v = *reinterpret_cast<const v4f*>(slab + ((size_t)((i * TN + j) * 4 + g) * TL::T + tid) * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[i][j][4 * g + c] += v[c];
                 }
-                if (p.out1) p.out1[(size_t)m * p.Cout + co] = v;
-                if (p.out2) p.out2[(size_t)m * p.Cout + co] = v * s2 + t2;
-            }
     }
-}
-
-// Sums the split-K slabs and applies the same epilogue (used by the 25088-deep FC and by deep,
-// small-M convolutions at low batch).
-__global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvArgs p) {
-    const long M = (long)p.B * p.Ho * p.Wo;
-    const long total = M * p.Cout;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(idx % p.Cout);
-        const long m = idx / p.Cout;
-        float acc = 0.f;
-        for (int s = 0; s < p.nsplit; ++s) acc += p.partial[(size_t)s * total + idx];
-        float v = apply_act(acc + (p.bias ? p.bias[co] : 0.f), p.act, p.slope ? p.slope[co] : 0.f);
-        if (p.res_mode == (int)ResMode::SAME) {
-            v += p.res[idx];
-        } else if (p.res_mode == (int)ResMode::UP2X) {
-            const int HoWo = p.Ho * p.Wo;
-            const int n = (int)(m / HoWo), rem = (int)(m - (long)n * HoWo);
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            v += p.res[((size_t)(n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout + co];
-        }
-        if (p.out1) p.out1[idx] = v;
-        if (p.out2) p.out2[idx] = v * p.s2[co] + p.t2[co];
-    }
+    const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+    conv_epilogue<BM, BN, WM, WN>(p, acc, tile_m * BM, tile_n * BN, wm, wn, lane);
 }
 
 int conv_wt_rows(int Cout) { return (Cout + 127) / 128 * 128; }
@@ -236,15 +343,55 @@ int conv_pick_cfg(long M, int Cout) {
     return 2;
 }
 
+static int g_num_cus = 0;
+static const float* g_zeros = nullptr;
+static int num_cus() {
+    if (!g_num_cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_num_cus = n;
+    }
+    return g_num_cus;
+}
+static const float* zero_line() {
+    if (!g_zeros) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 256) == hipSuccess) { (void)hipMemset(p, 0, 256); g_zeros = (const float*)p; }
+    }
+    return g_zeros;
+}
+
+size_t conv_slab_floats() { return (size_t)2 * 1280 * 128 * 128; }   // 2 segments x (<= 1280 stream-K workgroups) x largest tile
+
 template <int BM, int BN, int WM, int WN>
-static void launch_cfg(const ConvArgs& a, hipStream_t s) {
+static void launch_cfg(ConvArgs a, int resident_per_cu, hipStream_t s) {
     const long M = (long)a.B * a.Ho * a.Wo;
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (a.Cout + BN - 1) / BN;
+    const int T = tiles_m * tiles_n;
     const int chunks = a.Kpad / 32;
-    const int nsplit = a.nsplit < 1 ? 1 : a.nsplit;
-    const int cps = (chunks + nsplit - 1) / nsplit;
-    dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)nsplit);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks, cps);
+    const int S = num_cus() * resident_per_cu;
+    a.zeros = zero_line();
+    int full = (T / S) * S;
+    int R = T - full;
+    int sk_wgs = 0;
+    a.sk_units = 0; a.sk_q = 1;
+    if (R > 0 && R * 10 <= S * 9 && a.slabs && a.sk_enable) {   // worth it only if the last round is <= 90 % full
+        const long U = (long)R * chunks;
+        int q = (int)((U + S - 1) / S);
+        const int min_q = chunks < 8 ? chunks : 8;          // do not cut segments shorter than 8 chunks
+        if (q < min_q) q = min_q;
+        sk_wgs = (int)((U + q - 1) / q);
+        if (q >= chunks || (size_t)sk_wgs * 2 * BM * BN > conv_slab_floats()) {
+            sk_wgs = 0;                                     // whole tiles per workgroup anyway: plain tiles
+        } else {
+            a.sk_units = (int)U; a.sk_q = q;
+        }
+    }
+    if (sk_wgs == 0) { full = T; R = 0; }
+    a.sk_full = full;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3((unsigned)(full + sk_wgs)), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+    if (sk_wgs > 0)
+        hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, WM, WN>), dim3((unsigned)R), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
 }
 
 void launch_conv(const ConvArgs& a, int cfg, hipStream_t s) {
@@ -252,18 +399,11 @@ void launch_conv(const ConvArgs& a, int cfg, hipStream_t s) {
     if (M <= 0) return;
     if (cfg < 0) cfg = conv_pick_cfg(M, a.Cout);
     switch (cfg) {
-        case 0: launch_cfg<128, 128, 2, 2>(a, s); break;
-        case 1: launch_cfg<256, 64, 4, 1>(a, s); break;
-        case 2: launch_cfg<128, 32, 4, 1>(a, s); break;
-        default: launch_cfg<64, 64, 2, 2>(a, s); break;
+        case 0: launch_cfg<128, 128, 2, 2>(a, 2, s); break;
+        case 1: launch_cfg<256, 64, 4, 1>(a, 2, s); break;
+        case 2: launch_cfg<128, 32, 4, 1>(a, 4, s); break;
+        default: launch_cfg<64, 64, 2, 2>(a, 5, s); break;
     }
-    if (a.nsplit > 1) launch_splitk_finish(a, s);
-}
-
-void launch_splitk_finish(const ConvArgs& a, hipStream_t s) {
-    const long total = (long)a.B * a.Ho * a.Wo * a.Cout;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3(blocks), dim3(256), 0, s, a);
 }
 
 }  // namespace fh

@@ -51,8 +51,20 @@ void KernelTimer::collect(double* ms, double* flops, double* bytes, long long* l
     recs_.clear();
 }
 
+int KernelTimer::collect_ops(double* ms, double* flops, int* tag, int cap) {
+    int n = 0;
+    for (auto& r : recs_) {
+        FH_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        FH_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        if (n < cap) { ms[n] = t; flops[n] = r.flops; tag[n] = r.tag; ++n; }
+        pool_.push_back(r.a); pool_.push_back(r.b);
+    }
+    recs_.clear();
+    return n;
+}
+
 // ------------------------------------------------------------------------------------------ Net
-static constexpr size_t kPartialFloats = (size_t)2 * 512 * 128 * 128;
 
 Net::Net(const std::string& onnx_path, int default_h, int default_w) {
     OnnxModel m = load_onnx(onnx_path);
@@ -100,20 +112,9 @@ void Net::reserve(int max_batch) {
     if (max_batch <= cap_) return;
     cap_ = max_batch;
     arena_.ensure(plan_.arena_elems * (size_t)cap_ * sizeof(float));
-    partial_.ensure(kPartialFloats * sizeof(float));
+    partial_.ensure(conv_slab_floats() * sizeof(float));
     // the 4th input lane and alignment gaps must never hold NaNs
     FH_HIP(hipMemset(arena_.p, 0, arena_.bytes));
-}
-
-int Net::pick_split(const POp& op, int batch, int cfg) const {
-    static const int bm[4] = {128, 256, 128, 64}, bn[4] = {128, 64, 32, 64};
-    const long M = (long)batch * op.Ho * op.Wo;
-    const long tiles = ((M + bm[cfg] - 1) / bm[cfg]) * ((op.Cout + bn[cfg] - 1) / bn[cfg]);
-    const int chunks = conv_kpad(op.ks * op.ks * op.Cin) / 32;
-    if (tiles >= 256 || chunks < 16) return 1;
-    long ns = std::min<long>((512 + tiles - 1) / tiles, chunks / 8);
-    while (ns > 1 && (size_t)ns * M * op.Cout > kPartialFloats) --ns;
-    return (int)std::max<long>(1, ns);
 }
 
 void Net::run(int batch, hipStream_t s) {
@@ -139,14 +140,14 @@ void Net::run(int batch, hipStream_t s) {
                 a.out2 = op.out2 >= 0 ? tensor_ptr(op.out2) : nullptr;
                 a.s2 = d.has_aff ? P + d.s2 : nullptr;
                 a.t2 = d.has_aff ? P + d.t2 : nullptr;
-                a.partial = partial_.as<float>();
+                a.slabs = partial_.as<float>();
+                a.sk_enable = sk_enable ? 1 : 0;
                 a.B = batch; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
                 a.ks = op.ks; a.stride = op.stride; a.pad = op.pad; a.Kpad = d.Kpad;
                 a.act = (int)op.act; a.res_mode = (int)op.res_mode;
                 const long M = (long)batch * op.Ho * op.Wo;
                 int cfg = force_cfg >= 0 ? force_cfg : conv_pick_cfg(M, op.Cout);
-                if (force_cfg < 0 && cfg == 0 && ((M + 127) / 128) * ((op.Cout + 127) / 128) < 256) cfg = 3;   // few tiles: go finer
-                a.nsplit = pick_split(op, batch, cfg);
+                if (force_cfg < 0 && cfg == 0 && ((M + 127) / 128) * ((op.Cout + 127) / 128) < 128) cfg = 3;   // very few tiles: go finer
                 launch_conv(a, cfg, s);
                 tag = cfg;
                 break;
@@ -329,7 +330,7 @@ void Gallery::topk_dev(const float* q, int Q, int k, float* out_score, int* out_
         a.wt = qpack_.as<float>();
         a.out1 = dots_.as<float>();
         a.B = (int)g; a.H = a.W = a.Ho = a.Wo = 1; a.Cin = dim_; a.Cout = Q; a.ks = 1; a.stride = 1; a.pad = 0;
-        a.Kpad = dim_; a.nsplit = 1;
+        a.Kpad = dim_;
         launch_conv(a, -1, s);
         launch_topk_partial(dots_.as<float>(), g, Q, k, ps_.as<float>() + (size_t)part * Q * k, pi_.as<int>() + (size_t)part * Q * k,
                             base_ + r0, s);

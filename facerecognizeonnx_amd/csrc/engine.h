@@ -26,6 +26,8 @@ struct KernelTimer {
     void end(hipStream_t s, int tag, double flops, double bytes);
     // synchronises, aggregates elapsed ms / flops / bytes / launches per tag, then resets
     void collect(double* ms, double* flops, double* bytes, long long* launches);
+    // un-aggregated variant (tuning): one entry per recorded launch, in launch order
+    int collect_ops(double* ms, double* flops, int* tag, int cap);
     static KernelTimer& get();
 
   private:
@@ -60,6 +62,7 @@ class Net {
     int in_w() const { return plan_.inW; }
     int capacity() const { return cap_; }
     int force_cfg = -1;                                   // tuning hook: conv tile config override
+    bool sk_enable = true;                                // tuning hook: stream-K remainder wave
 
   private:
     struct DevOp {
@@ -68,7 +71,6 @@ class Net {
         int Kpad = 0;
     };
     float* tensor_ptr(int t) const { return arena_.as<float>() + plan_.tensors[t].offset * (size_t)cap_; }
-    int pick_split(const POp& op, int batch, int cfg) const;
     Plan plan_;
     std::vector<DevOp> dev_;
     DevBuf params_, arena_, partial_;

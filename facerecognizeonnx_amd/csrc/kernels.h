@@ -20,19 +20,22 @@ struct ConvArgs {
     float* out2;            // second output  out*s2 + t2, or null
     const float* s2;
     const float* t2;
-    float* partial;         // split-K slabs [nsplit][M][Cout] (only when nsplit > 1)
+    float* slabs;           // stream-K accumulator slabs (conv_slab_floats() floats) or null = plain tiles only
+    const float* zeros;     // >= 16 zero bytes (filled in by launch_conv)
     int B, H, W, Cin, Ho, Wo, Cout;
     int ks, stride, pad;
     int Kpad;               // multiple of 32
     int act;                // fh::Act
     int res_mode;           // fh::ResMode
-    int nsplit;             // >= 1
+    int sk_enable;          // allow the stream-K remainder wave
+    int sk_full, sk_units, sk_q;   // filled in by launch_conv: #plain tiles, remainder K-chunks, chunks per stream-K workgroup
 };
 
 // cfg: 0 = 128x128 tile, 1 = 256x64, 2 = 128x32, 3 = 64x64 (256 threads each); -1 = choose.
 void launch_conv(const ConvArgs& a, int cfg, hipStream_t s);
 int conv_pick_cfg(long M, int Cout);
 int conv_wt_rows(int Cout);                   // packed weight rows (Cout rounded up to 128)
+size_t conv_slab_floats();                    // size of the stream-K slab workspace
 inline int conv_kpad(int Ktot) { return (Ktot + 31) / 32 * 32; }
 
 // --------------------------------------------------------------------------------------------
@@ -90,8 +93,6 @@ void launch_resize_u8c3(const uint8_t* src, long src_stride, int sh, int sw, int
 
 // FaceRecognizer::normalize (src/face_recognizer.cpp:306-318), one wave per row
 void launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_t s);
-// FC split-K finish: sum slabs + bias → raw; (src/face_recognizer.cpp:286-297)
-void launch_splitk_finish(const ConvArgs& a, hipStream_t s);
 
 // compareFaces generalised to 1:N (src/face_recognizer.cpp:320-334): top-k of (dot+1)/2 ranked
 // (score desc, gallery index asc).  dots = [G][Q] raw dot products from launch_conv (gallery rows

@@ -127,11 +127,13 @@ FH_API int fh_gallery_topk_dev(fh_gallery* g, const float* d_queries, int nq, in
  * Tags 0..3 = conv_igemm tile configs (128x128, 256x64, 128x32, 64x64), 4 = depthwise conv,
  * 5 = other graph ops.  fh_timing_collect synchronises, fills 6-entry arrays (elapsed ms,
  * algorithmic FLOP, algorithmic activation bytes, launches) and resets the counters.
- * fh_*_set_conv_cfg forces one tile config for every dense conv of a handle (-1 = automatic). */
+ * fh_*_set_conv_cfg forces one tile config for every dense conv of a handle (-1 = automatic)
+ * and switches the stream-K remainder wave on/off (tuning / A-B measurements). */
 FH_API int fh_timing_enable(int on);
 FH_API int fh_timing_collect(double* ms, double* flops, double* bytes, long long* launches, int n);
-FH_API int fh_det_set_conv_cfg(fh_det* d, int cfg);
-FH_API int fh_rec_set_conv_cfg(fh_rec* r, int cfg);
+FH_API int fh_timing_collect_ops(double* ms, double* flops, int* tag, int cap);   /* per launch, in order */
+FH_API int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k);
+FH_API int fh_rec_set_conv_cfg(fh_rec* r, int cfg, int stream_k);
 
 /* ---- single kernels exposed for parity tests and micro-benchmarks (device pointers). */
 FH_API int fh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);   /* synchronous */

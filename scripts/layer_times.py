@@ -1,0 +1,44 @@
+"""Per-layer timing of one network (tuning aid): python scripts/layer_times.py rec|det [batch] [cfg]"""
+import ctypes as C, sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import facerecognizeonnx_amd as fa
+from facerecognizeonnx_amd.synth import models
+which = sys.argv[1] if len(sys.argv) > 1 else "rec"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else (256 if which == "rec" else 128)
+cfg = int(sys.argv[3]) if len(sys.argv) > 3 else -1
+sk = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+L = fa.lib(); L.fh_init(0)
+rng = np.random.default_rng(0)
+if which == "rec":
+    path = models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
+    net = fa.FaceRecognizer(); assert net.loadModel(path)
+    L.fh_rec_set_conv_cfg(net.handle, cfg, sk)
+    data = torch.from_numpy(rng.integers(0, 256, (B, 112, 112, 3), dtype=np.uint8)).cuda()
+    out = torch.zeros((B, 512), device="cuda")
+    run = lambda: net.embed_aligned_dev(data.data_ptr(), B, out.data_ptr())
+    desc = fa.plan_describe(path, 112, 112)
+else:
+    path = models.cached("det_500m_seed100.onnx", models.make_det_500m)
+    net = fa.FaceDetector(); assert net.loadModel(path)
+    L.fh_det_set_conv_cfg(net.handle, cfg, sk)
+    data = torch.from_numpy(rng.integers(0, 256, (B, 640, 640, 3), dtype=np.uint8)).cuda()
+    run = lambda: L.fh_det_run_network_dev(net.handle, data.data_ptr(), B, 640, 640, 1920, 640 * 1920, 0)
+    desc = fa.plan_describe(path, 640, 640)
+ops = [l for l in desc.splitlines()[1:] if l and l[0].isdigit()]
+for _ in range(3): run()
+torch.cuda.synchronize()
+L.fh_timing_enable(1)
+R = 5
+for _ in range(R): run()
+torch.cuda.synchronize()
+cap = 100000
+ms = (C.c_double * cap)(); fl = (C.c_double * cap)(); tg = (C.c_int * cap)()
+n = L.fh_timing_collect_ops(ms, fl, tg, cap)
+per = n // R
+tot = 0
+for i in range(per):
+    t = np.median([ms[r * per + i] for r in range(R)])
+    tot += t
+    print(f"{t*1e3:9.1f} us  {fl[i]/t/1e9 if t>0 else 0:7.1f} TF/s  cfg{tg[i]}  {ops[i] if i < len(ops) else ''}")
+print(f"total {tot:.3f} ms for batch {B}; {sum(fl[i] for i in range(per))/tot/1e9:.1f} TF/s overall")
