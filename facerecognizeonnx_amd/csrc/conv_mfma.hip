@@ -10,9 +10,9 @@
 // one input pixel: every global load is a full 16-byte lane access and 8 lanes cover one line.
 //
 // Tile anatomy (256 threads = 4 waves, >= 2 workgroups per CU):
-//   * global -> registers -> LDS, double buffered; one barrier per 32-deep K chunk.  Padding,
-//     ragged M and ragged K are resolved by redirecting the lane's load to a zero line (no
-//     branches in the loader).
+//   * global -> LDS directly (LDS-DMA, global_load_lds_dwordx4: no staging registers, no
+//     ds_write), double buffered; one barrier per 32-deep K chunk.  Padding, ragged M and ragged
+//     K are resolved by redirecting the lane's source address to a zero line (no branches).
 //   * LDS image [row][32 k] with the 16-byte column XOR-swizzled by (row>>1)&7, which makes the
 //     ds_read_b128 fragment reads of 32 different rows conflict-free (MI355X_MICROARCH.md §LDS).
 //   * each lane fetches 4 consecutive k of its row with ONE ds_read_b128 and feeds 4 MFMAs; the
@@ -47,6 +47,17 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == (int)Act::PRELU) return v >= 0.f ? v : v * slope;
     if (act == (int)Act::SIGMOID) return 1.0f / (1.0f + expf(-v));
     return v;
+}
+
+// global -> LDS without a register round trip (global_load_lds_dwordx4).  The global address is
+// per lane; the LDS address is the wave-uniform `dst` + 16 * lane.  (The builtin only exists in the
+// device pass; the host pass of hipcc just needs the kernel body to parse.)
+__device__ __forceinline__ void lds_dma16(const float* src, v4f* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#else
+    (void)src; (void)dst;
+#endif
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -127,20 +138,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvArgs p, const int tiles_n, const int chunks) {
+template <int BM, int BN, int WM, int WN, int OCC, bool FAST>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const ConvArgs p, const int tiles_n, const int chunks) {
     using TL = Tile<BM, BN, WM, WN>;
     constexpr int TM = TL::TM, TN = TL::TN, RP = TL::RP, AL = TL::AL, BL = TL::BL;
     __shared__ v4f lds[2][(BM + BN) * 8];
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep it scalar
     const int wm = wid / WN, wn = wid % WN;
     const int HoWo = p.Ho * p.Wo;
     const int M = p.B * HoWo;
     const int Ktot = p.ks * p.ks * p.Cin;
-    const bool cin32 = (p.Cin & 31) == 0;
-    const int lrow = tid >> 3, lq = tid & 7;
-    const int sw = lq ^ ((lrow >> 1) & 7);
+    const int lrow = tid >> 3;
+    const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);      // source k-column of this lane (swizzle on the source side)
     const int fr = lane & 31, fh2 = lane >> 5;
     const int fsw = (fr >> 1) & 7;
 
@@ -167,18 +178,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
         const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-        // ---- loader bookkeeping: this thread fills 16-byte column `lq` of rows lrow + i*RP
-        int a_base[AL];
+        // ---- loader bookkeeping.  LDS-DMA (global_load_lds_dwordx4) writes lane l of a wave at
+        // wave-uniform base + 16*l, i.e. pass i of wave `wid` fills rows i*RP + wid*8 + (l>>3), 16-byte
+        // column l&7 — the LDS image stays lane-linear and the XOR swizzle is applied to the SOURCE:
+        // the lane fetches k-column (l&7) ^ ((row>>1)&7)  (cdna_hip_programming.md §5.4 rule 21).
+        const float* a_ptr[AL];
         unsigned a_mask[AL];
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
             const int m = m0 + lrow + i * RP;
-            a_base[i] = 0; a_mask[i] = 0;
+            a_ptr[i] = p.zeros; a_mask[i] = 0;
             if (m < M) {
                 const int n = m / HoWo, rem = m - n * HoWo;
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-                a_base[i] = ((n * p.H + iy0) * p.W + ix0) * p.Cin;
+                a_ptr[i] = p.in + (long)(((n * p.H + iy0) * p.W + ix0) * p.Cin) + lqs * 4;
                 unsigned mk = 0;
                 if (p.ks == 3) {
 #pragma unroll
@@ -190,38 +204,64 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
                 a_mask[i] = mk;
             }
         }
-        const float* wrow[BL];
+        const float* w_ptr[BL];
 #pragma unroll
-        for (int i = 0; i < BL; ++i) wrow[i] = p.wt + (size_t)(n0 + lrow + i * RP) * p.Kpad + lq * 4;
+        for (int i = 0; i < BL; ++i) w_ptr[i] = p.wt + (size_t)(n0 + lrow + i * RP) * p.Kpad + lqs * 4 + (size_t)c_begin * 32;
 
-        v4f ra[AL], rb[BL];
-        auto load_chunk = [&](int kc) {
-            const int kb = kc * 32;
-            int tap, ci;
-            if (cin32) {                              // whole chunk inside one tap (wave-uniform)
-                tap = kb / p.Cin;
-                ci = kb - tap * p.Cin + lq * 4;
-            } else {
-                const int k4 = kb + lq * 4;
-                tap = k4 / p.Cin;
-                ci = k4 - tap * p.Cin;
-            }
-            const bool kvalid = kb + lq * 4 < Ktot;
-            int toff = ci;
-            if (p.ks == 3) { const int ky = tap / 3, kx = tap - ky * 3; toff += (ky * p.W + kx) * p.Cin; }
+        const unsigned long long zero_addr = (unsigned long long)p.zeros + (unsigned long long)(lane & 0) ;
+        v4f* const dstA = &lds[0][wid * 64];               // + buf*(BM+BN)*8 + i*RP*8; the hardware adds 16*lane
+        v4f* const dstB = &lds[0][BM * 8 + wid * 64];
+        // FAST path (Cin % 32 == 0): a chunk never straddles a tap, so tap / channel position are
+        // scalars that advance incrementally and the per-row source pointers are only rebuilt
+        // (valid tap -> real address, padded tap -> zero line) when the tap changes.
+        int ld_tap = 0, ld_ci = 0;
+        const float* cur[AL];
+        auto tap_setup = [&]() {
+            const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
+            const int toff = (p.ks == 3 ? (ky * p.W + kx) * p.Cin : 0) + ld_ci;
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
-                const float* src = (kvalid && ((a_mask[i] >> tap) & 1u)) ? p.in + (long)(a_base[i] + toff) : p.zeros;
-                ra[i] = *reinterpret_cast<const v4f*>(src);
+                const unsigned long long real = (unsigned long long)(a_ptr[i] + toff);
+                cur[i] = (const float*)(((a_mask[i] >> ld_tap) & 1u) ? real : zero_addr);
+            }
+        };
+        if (FAST) {
+            ld_tap = (c_begin * 32) / p.Cin;
+            ld_ci = c_begin * 32 - ld_tap * p.Cin;
+            tap_setup();
+        }
+        auto load_chunk = [&](int kc, int buf) {
+            v4f* const dA = dstA + buf * ((BM + BN) * 8);
+            v4f* const dB = dstB + buf * ((BM + BN) * 8);
+            if (FAST) {
+#pragma unroll
+                for (int i = 0; i < AL; ++i) { lds_dma16(cur[i], dA + i * RP * 8); cur[i] += 32; }
+#pragma unroll
+                for (int i = 0; i < BL; ++i) { lds_dma16(w_ptr[i], dB + i * RP * 8); w_ptr[i] += 32; }
+                ld_ci += 32;
+                if (ld_ci >= p.Cin) { ld_ci = 0; ++ld_tap; tap_setup(); }      // wave-uniform branch
+                return;
+            }
+            const int kb = kc * 32;
+            int tap, toff;                               // toff: float offset of this lane's 4 channels from a_ptr
+            if (p.ks == 1) { tap = 0; toff = kb; }
+            else {
+                const int k4 = kb + lqs * 4;
+                tap = k4 / p.Cin;
+                const int ci = k4 - tap * p.Cin;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                toff = (ky * p.W + kx) * p.Cin + ci - lqs * 4;
+            }
+            const bool kvalid = kb + lqs * 4 < Ktot;
+#pragma unroll
+            for (int i = 0; i < AL; ++i) {
+                // integer select (v_cndmask), not a branch: border lanes read the zero line
+                const unsigned long long real = (unsigned long long)(a_ptr[i] + toff);
+                const unsigned long long sel = (kvalid && ((a_mask[i] >> tap) & 1u)) ? real : zero_addr;
+                lds_dma16((const float*)sel, dA + i * RP * 8);
             }
 #pragma unroll
-            for (int i = 0; i < BL; ++i) rb[i] = *reinterpret_cast<const v4f*>(wrow[i] + kb);
-        };
-        auto store_chunk = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < AL; ++i) lds[buf][(lrow + i * RP) * 8 + sw] = ra[i];
-#pragma unroll
-            for (int i = 0; i < BL; ++i) lds[buf][BM * 8 + (lrow + i * RP) * 8 + sw] = rb[i];
+            for (int i = 0; i < BL; ++i) { lds_dma16(w_ptr[i], dB + i * RP * 8); w_ptr[i] += 32; }
         };
 
         v16f acc[TM][TN];
@@ -264,16 +304,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_igemm_kernel(const ConvA
         };
 
         if (c_begin < c_end) {
-            load_chunk(c_begin);
-            store_chunk(0);
-            __syncthreads();
+            load_chunk(c_begin, 0);
+            __syncthreads();                              // (drains vmcnt: the DMA of chunk 0 has landed)
             for (int kc = c_begin, it = 0; kc < c_end; ++kc, ++it) {
                 const int buf = it & 1;
-                const bool more = kc + 1 < c_end;
-                if (more) load_chunk(kc + 1);
+                if (kc + 1 < c_end) load_chunk(kc + 1, buf ^ 1);
                 compute(buf);
-                if (more) store_chunk(buf ^ 1);
-                __syncthreads();
+                __syncthreads();                          // all reads of `buf` done, DMA into buf^1 landed
             }
         }
 
@@ -353,17 +390,17 @@ static int num_cus() {
     }
     return g_num_cus;
 }
-static const float* zero_line() {
+static const float* zero_line() {                      // 8 KiB of zeros: a padded tap streams up to Cin*4 bytes from it
     if (!g_zeros) {
         void* p = nullptr;
-        if (hipMalloc(&p, 256) == hipSuccess) { (void)hipMemset(p, 0, 256); g_zeros = (const float*)p; }
+        if (hipMalloc(&p, 8192) == hipSuccess) { (void)hipMemset(p, 0, 8192); g_zeros = (const float*)p; }
     }
     return g_zeros;
 }
 
 size_t conv_slab_floats() { return (size_t)2 * 1280 * 128 * 128; }   // 2 segments x (<= 1280 stream-K workgroups) x largest tile
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int OCC>
 static void launch_cfg(ConvArgs a, int resident_per_cu, hipStream_t s) {
     const long M = (long)a.B * a.Ho * a.Wo;
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (a.Cout + BN - 1) / BN;
@@ -389,7 +426,10 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, hipStream_t s) {
     }
     if (sk_wgs == 0) { full = T; R = 0; }
     a.sk_full = full;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3((unsigned)(full + sk_wgs)), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+    if ((a.Cin & 31) == 0)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true>), dim3((unsigned)(full + sk_wgs)), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, false>), dim3((unsigned)(full + sk_wgs)), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
     if (sk_wgs > 0)
         hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, WM, WN>), dim3((unsigned)R), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
 }
@@ -399,10 +439,10 @@ void launch_conv(const ConvArgs& a, int cfg, hipStream_t s) {
     if (M <= 0) return;
     if (cfg < 0) cfg = conv_pick_cfg(M, a.Cout);
     switch (cfg) {
-        case 0: launch_cfg<128, 128, 2, 2>(a, 2, s); break;
-        case 1: launch_cfg<256, 64, 4, 1>(a, 2, s); break;
-        case 2: launch_cfg<128, 32, 4, 1>(a, 4, s); break;
-        default: launch_cfg<64, 64, 2, 2>(a, 5, s); break;
+        case 0: launch_cfg<128, 128, 2, 2, 2>(a, 2, s); break;
+        case 1: launch_cfg<256, 64, 4, 1, 2>(a, 2, s); break;
+        case 2: launch_cfg<128, 32, 4, 1, 4>(a, 4, s); break;
+        default: launch_cfg<64, 64, 2, 2, 4>(a, 5, s); break;
     }
 }
 
