@@ -1,0 +1,151 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol that
+include/facehip.h declares, the C++ ONNX reader + planner (no GPU calls), the reference-shaped
+error behaviour of the Python mirror classes, and the multi-rank host logic on gloo (world 2).
+"""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import facerecognizeonnx_amd as fa
+from facerecognizeonnx_amd import _lib
+from facerecognizeonnx_amd.synth import models
+from tests import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "facehip.h")).read()
+    declared = set(re.findall(r"FH_API\s+[\w\s\*]+?\b(fh_\w+)\s*\(", hdr))
+    assert len(declared) >= 40
+    L = fa.lib()
+    for name in declared:
+        assert hasattr(L, name), f"libfacehip.so does not export {name}"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert L.fh_version().startswith(b"facehip")
+    # sizes the ABI promises
+    assert fa.FACE_DTYPE.itemsize == 60 and L.fh_conv_wt_rows(20) == 128 and L.fh_conv_kpad(27) == 32
+
+
+def test_compare_faces_is_host_code_and_matches_reference_semantics():
+    r = fa.FaceRecognizer
+    e0 = np.zeros(512, np.float32); e0[0] = 1
+    e1 = np.zeros(512, np.float32); e1[1] = 1
+    assert r.compareFaces(e0, e0) == 1.0 and r.compareFaces(e0, e1) == 0.5 and r.compareFaces(e0, -e0) == 0.0
+    assert r.compareFaces(e0, e1[:10]) == 0.0 and r.compareFaces([], []) == 0.0      # size mismatch / empty -> 0
+    v = np.random.default_rng(0).standard_normal(512).astype(np.float32)
+    w = np.random.default_rng(1).standard_normal(512).astype(np.float32)
+    dot = np.float32(0)
+    for a, b in zip(v, w):                                                            # sequential fp32, as the reference
+        dot = np.float32(dot + np.float32(a * b))
+    assert r.compareFaces(v, w) == np.float32((dot + np.float32(1)) / np.float32(2))
+
+
+def test_unloaded_and_bad_models_fail_like_the_reference(tmp_path):
+    det, rec = fa.FaceDetector(), fa.FaceRecognizer()
+    img = util.frames_u8(1, 32, 32)[0]
+    assert len(det.detect(img)) == 0 and rec.extractFeature(img, fa.FaceBox()).size == 0   # "Model not loaded!"
+    assert rec.extractFeatureSimple(img).size == 0
+    assert not det.loadModel(str(tmp_path / "nope.onnx")) and "cannot open" in _lib.last_error()
+    junk = tmp_path / "junk.onnx"
+    junk.write_bytes(b"\x0a\x03abc\xff\xff\xff")
+    assert not rec.loadModel(str(junk)) and _lib.last_error()
+    trunc = tmp_path / "trunc.onnx"
+    trunc.write_bytes(open(os.path.join(util.GOLDEN, "tiny_scrfd.onnx"), "rb").read()[:5000])
+    assert not det.loadModel(str(trunc))
+
+
+def test_planner_iresnet_fusions(models_dir):
+    for fold in (True, False):
+        d = fa.plan_describe(util.tiny_iresnet(models_dir, fold_bn=fold), 112, 112)
+        ops = [l for l in d.splitlines() if re.match(r"^\d+ ", l)]
+        # 1 stem + 5 blocks x (conv1, conv2) + 4 downsample convs + FC; every BN / PRelu / Add is fused
+        assert len(ops) == 1 + 10 + 4 + 1, d
+        assert sum("CONV" in o for o in ops) == 15 and sum("GEMM" in o for o in ops) == 1
+        assert sum("+prelu" in o for o in ops) == 6 and sum("+res" in o for o in ops) == 5
+        assert sum("bn2nd" in o for o in ops) == 6 and sum("bn2nd-only" in o for o in ops) == 1
+        assert "out 683 [1x512]" in d
+    full = fa.plan_describe(models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50), 112, 112)
+    assert "ops 54" in full
+    gmac = float(re.search(r"GMAC/image ([\d.]+)", full).group(1))
+    assert abs(gmac - 6.309) < 0.005                                       # 6.309 GMAC / face
+
+
+def test_planner_scrfd_and_dynamic_input_defaults(models_dir):
+    dyn = util.tiny_scrfd(models_dir, hw=None)
+    d = fa.plan_describe(dyn, 640, 640)                                    # dynamic H/W -> caller's default (640)
+    assert d.startswith("input 640x640") and "out score_8 [12800x1]" in d and "out kps_32 [800x10]" in d
+    st = fa.plan_describe(util.tiny_scrfd(models_dir, hw=128), 640, 640)   # static shape wins over the default
+    assert st.startswith("input 128x128") and "out bbox_16 [128x4]" in st
+    assert st.count("+res(up2x)") == 2 and st.count("+sigmoid") == 3 and "UPSAMPLE" not in st and " ADD " not in st
+    full = fa.plan_describe(models.cached("det_500m_seed100.onnx", models.make_det_500m), 640, 640)
+    assert abs(float(re.search(r"GMAC/image ([\d.]+)", full).group(1)) - 0.7335) < 0.001
+    pre = fa.plan_describe(models.make_predecoded_det(os.path.join(models_dir, "pre.onnx"), 64, 7, True), 640, 640)
+    assert "out dets [64x15]" in pre
+
+
+def test_onnx_writer_reader_round_trip(models_dir):
+    from oracle import onnx_min
+    p = util.tiny_scrfd(models_dir, hw=None)
+    g = onnx_min.load(p)
+    assert g.inputs[0][1] == [1, 3, -1, -1] and len(g.outputs) == 9          # dim_param -> -1, like ORT reports
+    conv = next(n for n in g.nodes if n.op == "Conv")
+    assert conv.attrs["kernel_shape"] == [3, 3] and conv.attrs["strides"] == [2, 2] and conv.attrs["group"] == 1
+    rs = next(n for n in g.nodes if n.op == "Resize")
+    assert rs.attrs["mode"] == "nearest" and list(g.inits[rs.inputs[2]]) == [1, 1, 2, 2]
+    w = g.inits[conv.inputs[1]]
+    assert w.dtype == np.float32 and w.shape == (8, 3, 3, 3)
+
+
+def test_shard_ranges_cover_everything():
+    from facerecognizeonnx_amd.distributed import shard_range
+    for n in (0, 1, 7, 128, 1000003):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from facerecognizeonnx_amd.distributed import shard_range, allgather_queries, allgather_topk
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+rng = np.random.default_rng(0)
+G, Q, k, dim = 4000, 6, 5, 32
+gal = rng.standard_normal((G, dim)).astype(np.float32); gal /= np.linalg.norm(gal, axis=1, keepdims=True)
+gal[3100] = gal[40]                                              # duplicate rows on different shards: index tie-break
+allq = gal[[40, 999, 2500, 3999, 7, 3100]].copy()
+b, e = shard_range(Q, rank, world)
+q = allgather_queries(torch.from_numpy(allq[b:e]))               # each rank contributes Q/world queries
+assert np.array_equal(q.numpy(), allq)
+gb, ge = shard_range(G, rank, world)                             # row-sharded gallery
+sc = (q.numpy() @ gal[gb:ge].T + 1) / 2
+order = np.lexsort((np.arange(ge - gb)[None].repeat(Q, 0), -sc), axis=1)[:, :k]
+ls = np.take_along_axis(sc, order, 1).astype(np.float32); li = (order + gb).astype(np.int32)
+s, i = allgather_topk(torch.from_numpy(ls), torch.from_numpy(li), k)
+full = (allq @ gal.T + 1) / 2
+ref = np.lexsort((np.arange(G)[None].repeat(Q, 0), -full.astype(np.float32)), axis=1)[:, :k]
+assert np.array_equal(i.numpy(), ref), (rank, i.numpy(), ref)
+assert list(i.numpy()[0][:2]) == [40, 3100]
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_sharded_gallery_topk_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    port = 29500 + os.getpid() % 2000
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o

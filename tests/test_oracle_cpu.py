@@ -1,0 +1,263 @@
+"""CPU tests of the oracle: hand-derived known-answer tests and the golden
+fixtures evaluated independently with PyTorch fp64 (tests/golden/make_golden.py).
+
+The reference holds no golden vectors and cannot be built offline, so these KATs plus the fp64
+cross-check are what pins the restatement ("parity with ORT/OpenCV unpinned", oracle/oracle.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import onnx_min, oracle
+from tests import util
+
+G = util.GOLDEN
+
+
+# ------------------------------------------------------------------ preprocess (exact in fp32)
+def test_normalise_known_values():
+    img = np.zeros((2, 2, 3), np.uint8)
+    img[0, 0] = (0, 128, 255)            # B, G, R
+    out, scale = oracle.det_preprocess(img, 4, 4)
+    assert scale == 2.0
+    # (v - 127.5) / 128 : 0 -> -0.99609375, 128 -> 0.00390625, 255 -> 0.99609375; channel order RGB
+    pad = np.float32(-0.99609375)
+    rec = oracle.rec_preprocess(img)
+    assert rec[0, 0, 0] == np.float32(0.99609375) and rec[1, 0, 0] == np.float32(0.00390625) and rec[2, 0, 0] == pad
+    assert out.shape == (3, 4, 4) and np.all(out >= pad)
+
+
+def test_det_preprocess_letterbox_top_left_and_failure_paths():
+    img = util.frames_u8(1, 50, 100, seed=1)[0]
+    out, scale = oracle.det_preprocess(img, 64, 64)
+    assert scale == np.float32(0.64)
+    new_w, new_h = int(100 * np.float32(0.64)), int(50 * np.float32(0.64))
+    assert (new_w, new_h) == (64, 32)
+    assert np.all(out[:, new_h:, :] == np.float32(-0.99609375))          # zero canvas below the paste
+    same, s1 = oracle.det_preprocess(util.frames_u8(1, 64, 64, seed=2)[0], 64, 64)
+    assert s1 == 1.0
+    ref = (util.frames_u8(1, 64, 64, seed=2)[0][..., ::-1].transpose(2, 0, 1).astype(np.float32) - 127.5) / 128.0
+    assert np.array_equal(same, ref.astype(np.float32))                  # identity resize, BGR->RGB
+    assert oracle.det_preprocess(np.zeros((0, 0, 3), np.uint8), 64, 64) == (None, 1.0)
+    tiny = np.zeros((1, 1000, 3), np.uint8)                              # newH = int(1*0.064) = 0 -> failure, scale reset to 1
+    assert oracle.det_preprocess(tiny, 64, 64) == (None, 1.0)
+
+
+# ------------------------------------------------------------------ IoU / NMS (face_detector.cpp:340-384)
+def test_iou_integer_semantics():
+    assert oracle.iou((0, 0, 10, 10), (0, 0, 10, 10)) == 1.0
+    assert oracle.iou((0, 0, 10, 10), (5, 0, 10, 10)) == pytest.approx(50 / 150)
+    assert oracle.iou((0, 0, 10, 10), (10, 0, 10, 10)) == 0.0            # touching: no +1 convention
+    assert oracle.iou((0, 0, 10, 10), (20, 20, 5, 5)) == 0.0
+    assert np.isnan(oracle.iou((3, 3, 0, 0), (3, 3, 0, 0)))              # 0/0 -> NaN -> never suppresses
+    assert oracle.iou((0, 0, -4, 5), (0, 0, 10, 10)) == 0.0              # negative width (x2 < x1 after truncation)
+
+
+def _faces(rows):
+    f = np.zeros(len(rows), oracle.FACE_DTYPE)
+    for i, (x, y, w, h, s) in enumerate(rows):
+        f[i]["x"], f[i]["y"], f[i]["w"], f[i]["h"], f[i]["score"] = x, y, w, h, s
+        f[i]["lm"] = i
+    return f
+
+
+def test_nms_greedy_strict_and_ordered():
+    f = _faces([(0, 0, 10, 10, 0.6), (1, 0, 10, 10, 0.9), (100, 100, 10, 10, 0.7), (0, 0, 10, 10, 0.5)])
+    out = oracle.nms(f, 0.4)
+    assert [round(float(s), 1) for s in out["score"]] == [0.9, 0.7]      # score-descending survivors
+    # iou exactly == threshold does NOT suppress (strict >): boxes overlap 50/150 = 1/3
+    g = _faces([(0, 0, 10, 10, 0.9), (5, 0, 10, 10, 0.8)])
+    assert len(oracle.nms(g, float(np.float32(50) / np.float32(150)))) == 2
+    assert len(oracle.nms(g, 0.33)) == 1
+    # ties: candidate index ascending (the total order this build fixes for the unstable std::sort)
+    t = _faces([(0, 0, 5, 5, 0.5), (50, 0, 5, 5, 0.5), (100, 0, 5, 5, 0.5)])
+    assert list(oracle.nms(t, 0.4)["lm"][:, 0]) == [0, 1, 2]
+    # degenerate zero-area duplicates are never suppressed (NaN > thr is false)
+    z = _faces([(3, 3, 0, 0, 0.9), (3, 3, 0, 0, 0.8)])
+    assert len(oracle.nms(z, 0.4)) == 2
+    assert len(oracle.nms(_faces([]), 0.4)) == 0
+
+
+def test_postprocess_truncation_and_threshold():
+    rows = np.zeros((4, 15), np.float32)
+    rows[0] = [-0.5, -0.9, 10.7, 20.2, 0.9] + list(range(10))           # int(-0.5) = 0, w = int(11.2) = 11
+    rows[1] = [5, 5, 3, 9, 0.8] + [0] * 10                               # x2 < x1 -> negative width kept
+    rows[2] = [1, 1, 2, 2, 0.5] + [0] * 10                               # score == thr is dropped (strict >)
+    rows[3] = [8.9, 8.9, 20, 20, 0.7] + [0] * 10
+    f = oracle.threshold_rows(rows, 1.0, 0.5)
+    assert len(f) == 3
+    assert (f[0]["x"], f[0]["y"], f[0]["w"], f[0]["h"]) == (0, 0, 11, 21)
+    assert (f[1]["w"], f[1]["h"]) == (-2, 4)
+    assert (f[2]["x"], f[2]["w"]) == (8, 11)
+    g = oracle.threshold_rows(rows, 0.5, 0.5)                            # /scale before truncation
+    assert (g[0]["w"], g[0]["h"]) == (int(np.float32(10.7) / 0.5 - np.float32(-0.5) / 0.5), 42)
+    np.testing.assert_array_equal(g[0]["lm"], np.arange(10, dtype=np.float32) / 0.5)
+    assert len(oracle.threshold_rows(np.zeros((3, 14), np.float32), 1.0, -1.0)) == 0   # featDim < 15 -> nothing
+
+
+def test_scrfd_decode_formula():
+    rng = np.random.default_rng(0)
+    H = W = 64
+    outs = []
+    for cols in (1, 4, 10):
+        for s in (8, 16, 32):
+            outs.append(rng.standard_normal(((H // s) * (W // s) * 2, cols)).astype(np.float32))
+    rows = oracle.scrfd_decode(outs, H, W)
+    assert rows.shape == (sum(o.shape[0] for o in outs[:3]), 15)
+    # independent numpy re-derivation of distance2bbox / distance2kps
+    r = 0
+    for si, s in enumerate((8, 16, 32)):
+        gw = W // s
+        n = outs[si].shape[0]
+        idx = np.arange(n)
+        cx = ((idx // 2) % gw * s).astype(np.float32); cy = ((idx // 2) // gw * s).astype(np.float32)
+        d, k = outs[3 + si], outs[6 + si]
+        exp = np.concatenate([np.stack([cx - d[:, 0] * s, cy - d[:, 1] * s, cx + d[:, 2] * s, cy + d[:, 3] * s, outs[si][:, 0]], 1),
+                              np.stack([cx if j % 2 == 0 else cy for j in range(10)], 1) + k * s], 1).astype(np.float32)
+        assert np.array_equal(rows[r:r + n], exp)
+        r += n
+
+
+# ------------------------------------------------------------------ alignment (face_recognizer.cpp:93-133)
+def test_similarity_identity_and_closed_form():
+    M = oracle.estimate_similarity(util.TEMPLATE)
+    np.testing.assert_allclose(M, [[1, 0, 0], [0, 1, 0]], atol=1e-12)
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        s, th = rng.uniform(0.3, 3), rng.uniform(-np.pi, np.pi)
+        R = s * np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+        t = rng.uniform(-50, 300, 2)
+        src = ((util.TEMPLATE.astype(np.float64) - t) @ np.linalg.inv(R).T).astype(np.float32)
+        src += rng.normal(0, 0.3, src.shape).astype(np.float32)          # all five stay inliers (< 3 px in template space)
+        M = oracle.estimate_similarity(src)
+        # independent least squares on the linear 4-DoF model [a, b, tx, ty]
+        A = np.zeros((10, 4)); y = np.zeros(10)
+        for p in range(5):
+            x_, y_ = float(src[p, 0]), float(src[p, 1])
+            A[2 * p] = [x_, -y_, 1, 0]; A[2 * p + 1] = [y_, x_, 0, 1]
+            y[2 * p], y[2 * p + 1] = float(util.TEMPLATE[p, 0]), float(util.TEMPLATE[p, 1])
+        a, b, tx, ty = np.linalg.lstsq(A, y, rcond=None)[0]
+        np.testing.assert_allclose(M, [[a, -b, tx], [b, a, ty]], rtol=1e-9, atol=1e-9)
+
+
+def test_similarity_rejects_outlier_and_degenerate():
+    src = util.TEMPLATE.copy() * 2 + 30
+    clean = oracle.estimate_similarity(src)
+    bad = src.copy(); bad[2] += (40, -35)                               # nose far off: > 3 px after mapping
+    M = oracle.estimate_similarity(bad)
+    A = np.zeros((8, 4)); y = np.zeros(8)
+    for q, p in enumerate((0, 1, 3, 4)):                                 # refit on the 4 inliers only
+        A[2 * q] = [bad[p, 0], -bad[p, 1], 1, 0]; A[2 * q + 1] = [bad[p, 1], bad[p, 0], 0, 1]
+        y[2 * q], y[2 * q + 1] = util.TEMPLATE[p]
+    a, b, tx, ty = np.linalg.lstsq(A, y, rcond=None)[0]
+    np.testing.assert_allclose(M, [[a, -b, tx], [b, a, ty]], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(M, clean, atol=1e-6)
+    assert oracle.estimate_similarity(np.full((5, 2), 7.0, np.float32)) is None   # coincident points -> empty Mat
+
+
+def test_warp_identity_translation_and_border():
+    img = util.frames_u8(1, 150, 200, seed=3)[0]
+    ident = oracle.warp_affine(img, np.array([[1, 0, 0], [0, 1, 0]], np.float64))
+    assert np.array_equal(ident, img[:112, :112])                        # M = I -> top-left 112x112 crop
+    sh = oracle.warp_affine(img, np.array([[1, 0, -10], [0, 1, -20]], np.float64))
+    assert np.array_equal(sh, img[20:132, 10:122])                       # dst(x,y) = src(x+10, y+20)
+    out = oracle.warp_affine(img, np.array([[1, 0, 50], [0, 1, 60]], np.float64))
+    assert np.all(out[:60] == 0) and np.all(out[:, :50] == 0)            # constant-0 border
+    assert np.array_equal(out[60:, 50:], img[:52, :62])
+    half = oracle.warp_affine(img, np.array([[1, 0, -0.5], [0, 1, 0]], np.float64))
+    exp = ((img[:112, :112].astype(np.int32) + img[:112, 1:113].astype(np.int32)) * 16384 + 16384) >> 15
+    assert np.array_equal(half, exp.astype(np.uint8))                    # 1/32-px grid, (sum + 2^14) >> 15
+
+
+def test_align_face_template_and_fallback():
+    img = util.frames_u8(1, 200, 200, seed=4)[0]
+    f = np.zeros(1, oracle.FACE_DTYPE)
+    f["lm"] = util.TEMPLATE.reshape(1, 10)
+    assert np.array_equal(oracle.align_face(img, f[0]), img[:112, :112])
+    f["lm"] = 9.0                                                        # no transform -> crop face.box & image, resize
+    f["x"], f["y"], f["w"], f["h"] = 150, 160, 100, 100
+    fb = oracle.align_face(img, f[0])
+    assert np.array_equal(fb, oracle.resize_bilinear(img[160:200, 150:200], 112, 112))
+    f["x"] = 500
+    assert oracle.align_face(img, f[0]) is None
+    assert oracle.align_face(np.zeros((0, 0, 3), np.uint8), f[0]) is None
+
+
+def test_resize_same_size_area_and_reference_formula():
+    img = util.frames_u8(1, 40, 60, seed=6)[0]
+    assert np.array_equal(oracle.resize_bilinear(img, 60, 40), img)
+    half = oracle.resize_bilinear(img, 30, 20)                           # exact 2x -> INTER_AREA: rounded 2x2 mean
+    a = img.astype(np.int32)
+    exp = (a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(half, exp.astype(np.uint8))
+    up = oracle.resize_bilinear(img, 120, 80)
+    fl = _float_bilinear(img, 120, 80)
+    assert np.abs(up.astype(np.int32) - np.rint(fl).astype(np.int32)).max() <= 1     # fixed point vs float: <= 1 grey level
+    assert np.array_equal(oracle.resize_bilinear(np.full((7, 9, 3), 200, np.uint8), 33, 21), np.full((21, 33, 3), 200, np.uint8))
+
+
+def _float_bilinear(img, dw, dh):
+    sh, sw = img.shape[:2]
+    x = np.clip((np.arange(dw) + 0.5) * sw / dw - 0.5, 0, sw - 1); y = np.clip((np.arange(dh) + 0.5) * sh / dh - 0.5, 0, sh - 1)
+    x0 = np.floor(x).astype(int); y0 = np.floor(y).astype(int)
+    x1 = np.minimum(x0 + 1, sw - 1); y1 = np.minimum(y0 + 1, sh - 1)
+    fx = (x - x0)[None, :, None]; fy = (y - y0)[:, None, None]
+    a = img.astype(np.float64)
+    return (a[y0][:, x0] * (1 - fx) + a[y0][:, x1] * fx) * (1 - fy) + (a[y1][:, x0] * (1 - fx) + a[y1][:, x1] * fx) * fy
+
+
+# ------------------------------------------------------------------ normalize / compare (face_recognizer.cpp:306-334)
+def test_normalize_and_compare():
+    v = np.arange(1, 513, dtype=np.float32)
+    n = oracle.l2_normalize(v)
+    assert abs(float(np.linalg.norm(n.astype(np.float64))) - 1) < 1e-6
+    assert np.array_equal(oracle.l2_normalize(np.zeros(8, np.float32)), np.zeros(8, np.float32))   # norm 0: untouched
+    assert oracle.compare(n, n) == pytest.approx(1.0, abs=1e-6)
+    e0 = np.zeros(512, np.float32); e0[0] = 1; e1 = np.zeros(512, np.float32); e1[1] = 1
+    assert oracle.compare(e0, e1) == 0.5 and oracle.compare(e0, -e0) == 0.0
+    assert oracle.compare(e0, e1[:100]) == 0.0 and oracle.compare(np.zeros(0, np.float32), np.zeros(0, np.float32)) == 0.0
+
+
+def test_gallery_topk_order():
+    rng = np.random.default_rng(2)
+    gal = rng.standard_normal((300, 32)).astype(np.float32); gal /= np.linalg.norm(gal, axis=1, keepdims=True)
+    q = gal[[5, 17]].copy(); gal[200] = gal[5]
+    s, i = oracle.gallery_topk(q, gal, 4)
+    assert list(i[0][:2]) == [5, 200] and i[1][0] == 17
+    assert np.all(np.diff(s, axis=1) <= 0)
+    s2, i2 = oracle.gallery_topk(q, gal[:3], 4)                          # fewer rows than k: padded with (-1, -1)
+    assert list(i2[0]) == sorted(i2[0][:3], key=lambda j: -float(np.dot(q[0], gal[j]))) + [-1] and s2[0][3] == -1
+
+
+# ------------------------------------------------------------------ graph operators vs PyTorch fp64 goldens
+def test_golden_iresnet_matches_torch_fp64():
+    g = onnx_min.load(os.path.join(G, "tiny_iresnet.onnx"))
+    io = np.load(os.path.join(G, "tiny_iresnet_io.npz"))
+    assert sorted({n.op for n in g.nodes}) == ["Add", "BatchNormalization", "Conv", "Flatten", "Gemm", "PRelu"]
+    out = oracle.run_graph(g, {"input.1": io["x"]})["683"]
+    np.testing.assert_allclose(out, io["y"], rtol=2e-5, atol=2e-5)
+
+
+def test_golden_scrfd_matches_torch_fp64():
+    g = onnx_min.load(os.path.join(G, "tiny_scrfd.onnx"))
+    io = np.load(os.path.join(G, "tiny_scrfd_io.npz"))
+    assert {n.op for n in g.nodes} == {"Conv", "Relu", "Add", "Resize", "Sigmoid", "Transpose", "Reshape"}
+    assert [n for n, _ in g.outputs] == [f"{k}_{s}" for k in ("score", "bbox", "kps") for s in (8, 16, 32)]
+    out = oracle.run_graph(g, {"input.1": io["x"]})
+    for name in out:
+        np.testing.assert_allclose(out[name], io[name], rtol=2e-5, atol=2e-5, err_msg=name)
+
+
+def test_oracle_classes_follow_reference_error_behaviour(models_dir):
+    det, rec = oracle.OracleDetector(), oracle.OracleRecognizer()
+    assert not det.loadModel(os.path.join(models_dir, "missing.onnx"))
+    assert len(det.detect(util.frames_u8(1, 32, 32)[0])) == 0            # "Model not loaded!"
+    assert det.loadModel(os.path.join(G, "tiny_scrfd.onnx")) and (det.inW, det.inH) == (64, 64)   # static shape adopted
+    assert len(det.detect(np.zeros((0, 0, 3), np.uint8))) == 0
+    faces = det.detect(util.frames_u8(1, 90, 70, seed=8, smooth=True)[0], 0.3, 0.4)
+    assert len(faces) > 0 and np.all(np.diff(faces["score"]) <= 0)       # faces[0] is the best face (main.cpp:101)
+    assert rec.loadModel(os.path.join(G, "tiny_iresnet.onnx")) and (rec.inW, rec.inH) == (112, 112)
+    f = rec.extractFeature(util.frames_u8(1, 90, 70, seed=8, smooth=True)[0], faces[0])
+    assert f.shape == (64,) and abs(float(np.linalg.norm(f)) - 1) < 1e-5
+    assert rec.extractFeature(None, faces[0]).size == 0
