@@ -83,6 +83,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
     float* __restrict__ out1 = p.out1;
     float* __restrict__ out2 = p.out2;
     const bool vec = (p.Cout & 3) == 0;
+    if (p.n_outs > 0) {                                  // merged sibling convs: per-channel-range destination
+#pragma unroll
+        for (int i = 0; i < TL::TM; ++i) {
+            const int m = m0 + (wm * TL::TM + i) * 32 + fr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < TL::TN; ++j) {
+                const int cb = n0 + (wn * TL::TN + j) * 32 + 4 * fh2;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int co = cb + 8 * (e >> 2) + (e & 3);
+                    if (co >= p.Cout) continue;
+                    const int g = co >= p.oc0[2] && p.n_outs > 2 ? 2 : co >= p.oc0[1] ? 1 : 0;
+                    const int cg = p.oc0[g + 1] - p.oc0[g];
+                    const float v = apply_act(acc[i][j][e] + p.bias[co], p.oact[g], 0.f);
+                    p.outs[g][(size_t)m * cg + (co - p.oc0[g])] = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TL::TM; ++i) {
         const int m = m0 + (wm * TL::TM + i) * 32 + fr;

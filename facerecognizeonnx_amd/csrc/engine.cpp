@@ -145,6 +145,9 @@ void Net::run(int batch, hipStream_t s) {
                 a.B = batch; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
                 a.ks = op.ks; a.stride = op.stride; a.pad = op.pad; a.Kpad = d.Kpad;
                 a.act = (int)op.act; a.res_mode = (int)op.res_mode;
+                a.n_outs = (int)op.outs.size();
+                for (int g = 0; g < a.n_outs && g < 3; ++g) { a.outs[g] = tensor_ptr(op.outs[g]); a.oact[g] = op.out_act[g]; a.oc0[g] = op.out_c0[g]; }
+                if (a.n_outs > 0) a.oc0[a.n_outs] = op.out_c0[a.n_outs];
                 const long M = (long)batch * op.Ho * op.Wo;
                 int cfg = force_cfg >= 0 ? force_cfg : conv_pick_cfg(M, op.Cout);
                 if (force_cfg < 0 && cfg == 0 && ((M + 127) / 128) * ((op.Cout + 127) / 128) < 128) cfg = 3;   // very few tiles: go finer

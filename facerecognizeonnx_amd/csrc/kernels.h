@@ -27,6 +27,10 @@ struct ConvArgs {
     int Kpad;               // multiple of 32
     int act;                // fh::Act
     int res_mode;           // fh::ResMode
+    int n_outs;             // > 0: merged sibling convs — channels [oc0[g], oc0[g+1]) go to outs[g] with act oact[g]
+    float* outs[3];
+    int oc0[4];
+    int oact[3];
     int sk_enable;          // allow the stream-K remainder wave
     int sk_full, sk_units, sk_q;   // filled in by launch_conv: #plain tiles, remainder K-chunks, chunks per stream-K workgroup
 };

@@ -24,44 +24,70 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
     return v;
 }
 
+// Depthwise 3x3 (+bias +ReLU).  One thread = 4 channels x a strip of STRIP output pixels along x:
+// the 3 x (STRIP*stride + 2) input float4s are loaded once and reused across the strip (4.5
+// instead of 9 loads per output at stride 1), weights stay in registers.  Lanes run over the
+// channel groups first, so a wave's loads cover whole 64..128-byte pixel rows.
+template <int STRIDE, int STRIP>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        int B, int H, int W, int C, int Ho, int Wo, int stride, int act) {
+                                                        int B, int H, int W, int C, int Ho, int Wo, int act) {
+    constexpr int COLS = (STRIP - 1) * STRIDE + 3;
     const int C4 = C >> 2;
-    const long total = (long)B * Ho * Wo * C4;
+    const int strips = (Wo + STRIP - 1) / STRIP;
+    const long total = (long)B * Ho * strips * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % C4);
-        long pix = idx / C4;
-        const int ox = (int)(pix % Wo); pix /= Wo;
-        const int oy = (int)(pix % Ho);
-        const int n = (int)(pix / Ho);
-        v4f acc = *reinterpret_cast<const v4f*>(bias + c4 * 4);
-        const int iy0 = oy * stride - 1, ix0 = ox * stride - 1;
+        long r = idx / C4;
+        const int sx = (int)(r % strips); r /= strips;
+        const int oy = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        const int ox0 = sx * STRIP;
+        v4f wk[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const v4f*>(w + t * C + c4 * 4);
+        const v4f b4 = *reinterpret_cast<const v4f*>(bias + c4 * 4);
+        v4f acc[STRIP];
+#pragma unroll
+        for (int o = 0; o < STRIP; ++o) acc[o] = b4;
+        const int iy0 = oy * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = iy0 + ky;
             if ((unsigned)iy >= (unsigned)H) continue;
+            const float* rowp = in + ((size_t)n * H + iy) * W * C + c4 * 4;
+            v4f x[COLS];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ix0 + kx;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                const v4f x = *reinterpret_cast<const v4f*>(in + (((size_t)n * H + iy) * W + ix) * C + c4 * 4);
-                const v4f ww = *reinterpret_cast<const v4f*>(w + (ky * 3 + kx) * C + c4 * 4);
-                acc += x * ww;
+            for (int cidx = 0; cidx < COLS; ++cidx) {
+                const int ix = ix0 + cidx;
+                x[cidx] = (unsigned)ix < (unsigned)W ? *reinterpret_cast<const v4f*>(rowp + (size_t)ix * C) : v4f{0.f, 0.f, 0.f, 0.f};
             }
+#pragma unroll
+            for (int o = 0; o < STRIP; ++o)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[o] += x[o * STRIDE + kx] * wk[ky * 3 + kx];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[e] = act1(acc[e], act, 0.f);
-        *reinterpret_cast<v4f*>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4) = acc;
+        for (int o = 0; o < STRIP; ++o) {
+            const int ox = ox0 + o;
+            if (ox >= Wo) break;
+            v4f v = acc[o];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act1(v[e], act, 0.f);
+            *reinterpret_cast<v4f*>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4) = v;
+        }
     }
 }
 
 void launch_dwconv3x3(const float* in, const float* w9c, const float* bias, float* out, int B, int H, int W, int C,
                       int stride, int act, hipStream_t s) {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-    const long total = (long)B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo,
-                       stride, act);
+    constexpr int STRIP = 4;
+    const long total = (long)B * Ho * ((Wo + STRIP - 1) / STRIP) * (C / 4);
+    if (stride == 1)
+        hipLaunchKernelGGL((dwconv3x3_kernel<1, STRIP>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo, act);
+    else
+        hipLaunchKernelGGL((dwconv3x3_kernel<2, STRIP>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo, act);
 }
 
 // generic per-channel pass, scalar channel indexing (C need not be a multiple of 4)

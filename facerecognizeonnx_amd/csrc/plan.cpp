@@ -440,6 +440,50 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
         }
     }
 
+    // ---------------------------------------------------------------- 7b. horizontal merge of small sibling convs
+    {
+        std::vector<bool> gone(P.ops.size(), false);
+        for (size_t i = 0; i < P.ops.size(); ++i) {
+            POp& a = P.ops[i];
+            auto eligible = [](const POp& o) {
+                return o.kind == OpKind::CONV && o.res < 0 && o.out2 < 0 && o.out >= 0 && o.slope.empty() && o.outs.empty();
+            };
+            if (gone[i] || !eligible(a)) continue;
+            std::vector<size_t> grp{i};
+            int ctot = a.Cout;
+            for (size_t j = i + 1; j < P.ops.size(); ++j) {
+                const POp& b = P.ops[j];
+                if (gone[j] || !eligible(b) || b.in != a.in || b.ks != a.ks || b.stride != a.stride || b.pad != a.pad) continue;
+                if (ctot + b.Cout > 32 || grp.size() >= 3) continue;
+                // the sibling must not depend on anything produced between i and j (it only reads `in`)
+                grp.push_back(j);
+                ctot += b.Cout;
+            }
+            if (grp.size() < 2) continue;
+            const int taps = a.ks * a.ks, kin = taps * a.Cin;
+            POp m = a;
+            m.name = a.name + "+merged";
+            m.weight.assign((size_t)ctot * kin, 0.f);
+            m.bias.assign((size_t)ctot, 0.f);
+            m.out = -1; m.act = Act::NONE; m.Cout = ctot; m.macs = 0;
+            int c0 = 0;
+            for (size_t g : grp) {
+                const POp& b = P.ops[g];
+                std::copy(b.weight.begin(), b.weight.end(), m.weight.begin() + (size_t)c0 * kin);
+                std::copy(b.bias.begin(), b.bias.end(), m.bias.begin() + c0);
+                m.outs.push_back(b.out); m.out_c0.push_back(c0); m.out_act.push_back((int)b.act);
+                m.macs += b.macs;
+                c0 += b.Cout;
+                if (g != i) gone[g] = true;
+            }
+            m.out_c0.push_back(c0);
+            P.ops[i] = std::move(m);
+        }
+        std::vector<POp> kept;
+        for (size_t i = 0; i < P.ops.size(); ++i) if (!gone[i]) kept.push_back(std::move(P.ops[i]));
+        P.ops.swap(kept);
+    }
+
     // ---------------------------------------------------------------- 8. outputs
     for (const auto& o : m.outputs) {
         auto it = vals.find(o.name);
@@ -458,7 +502,9 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
     // ---------------------------------------------------------------- 9. liveness + arena
     for (size_t i = 0; i < P.ops.size(); ++i) {
         const POp& op = P.ops[i];
-        for (int t : {op.in, op.in2, op.res, op.out, op.out2}) {
+        std::vector<int> touched{op.in, op.in2, op.res, op.out, op.out2};
+        touched.insert(touched.end(), op.outs.begin(), op.outs.end());
+        for (int t : touched) {
             if (t < 0) continue;
             PTensor& pt = P.tensors[t];
             if (pt.first < 0) pt.first = (int)i;
@@ -498,6 +544,7 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
     for (auto& op : P.ops) {
         double b = 0;
         for (int t : {op.in, op.in2, op.res, op.out, op.out2}) if (t >= 0) b += (double)P.tensors[t].elems() * 4;
+        for (int t : op.outs) b += (double)P.tensors[t].elems() * 4;
         op.bytes = b;
         P.macs += op.macs;
         P.act_bytes += b;
@@ -517,6 +564,7 @@ std::string Plan::describe() const {
         const POp& o = ops[i];
         os << i << " " << kinds[(int)o.kind] << " k" << o.ks << "s" << o.stride << " " << o.H << "x" << o.W << "x" << o.Cin
            << " -> " << o.Ho << "x" << o.Wo << "x" << o.Cout << acts[(int)o.act];
+        if (!o.outs.empty()) os << " [merged x" << o.outs.size() << "]";
         if (o.res >= 0) os << (o.res_mode == ResMode::UP2X ? " +res(up2x)" : " +res");
         if (o.out2 >= 0) os << (o.out >= 0 ? " +bn2nd" : " bn2nd-only");
         os << "  MMAC " << o.macs * 1e-6 << "\n";

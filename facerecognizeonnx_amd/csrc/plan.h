@@ -40,6 +40,10 @@ struct POp {
     //  GEMM  : weight[N][K], K re-ordered to the NHWC flatten of the producer
     //  AFFINE: s2/t2 applied to `in`
     std::vector<float> weight, bias, slope, s2, t2;
+    // Horizontally merged sibling convolutions (same input, same geometry, sum(Cout) <= 32, e.g. the
+    // SCRFD cls/reg/kps branches): one GEMM with Cout = sum, channel range [out_c0[g], out_c0[g+1]) goes
+    // to tensor outs[g] with activation out_act[g].  Empty = ordinary single-output conv.
+    std::vector<int> outs, out_c0, out_act;
     double macs = 0;                  // multiply-accumulates per image
     double bytes = 0;                 // algorithmic activation bytes per image (in + res + outs)
 };

@@ -81,7 +81,7 @@ def test_planner_scrfd_and_dynamic_input_defaults(models_dir):
     assert d.startswith("input 640x640") and "out score_8 [12800x1]" in d and "out kps_32 [800x10]" in d
     st = fa.plan_describe(util.tiny_scrfd(models_dir, hw=128), 640, 640)   # static shape wins over the default
     assert st.startswith("input 128x128") and "out bbox_16 [128x4]" in st
-    assert st.count("+res(up2x)") == 2 and st.count("+sigmoid") == 3 and "UPSAMPLE" not in st and " ADD " not in st
+    assert st.count("+res(up2x)") == 2 and st.count("[merged x3]") == 3 and "UPSAMPLE" not in st and " ADD " not in st
     full = fa.plan_describe(models.cached("det_500m_seed100.onnx", models.make_det_500m), 640, 640)
     assert abs(float(re.search(r"GMAC/image ([\d.]+)", full).group(1)) - 0.7335) < 0.001
     pre = fa.plan_describe(models.make_predecoded_det(os.path.join(models_dir, "pre.onnx"), 64, 7, True), 640, 640)
