@@ -335,3 +335,31 @@ def test_pipeline_and_gallery(models_dir):
     assert np.array_equal(ix.cpu().numpy(), ri)
     np.testing.assert_allclose(sc.cpu().numpy(), rs, atol=2e-6)
     assert list(ri[0][:2]) == [123, 4000]
+
+
+def test_cpp_shim_matches_python_api(models_dir, tmp_path):
+    """The reference-shaped C++ classes (shim/face_detector.h, face_recognizer.h) run main.cpp's compare flow."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(fa.__file__), "shim_demo")
+    assert os.path.exists(exe), "shim_demo not built (make -C facerecognizeonnx_amd/csrc)"
+    dpath = util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0)
+    rpath = util.tiny_iresnet(models_dir)
+    imgs = util.frames_u8(2, 120, 160, seed=77, smooth=True)
+    pa, pb = str(tmp_path / "a.bgr"), str(tmp_path / "b.bgr")
+    imgs[0].tofile(pa); imgs[1].tofile(pb)
+    out = subprocess.run([exe, dpath, rpath, pa, "120", "160", pb, "120", "160", "0.5"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+    det = fa.FaceDetector(); rec = fa.FaceRecognizer()
+    assert det.loadModel(dpath) and rec.loadModel(rpath)
+    fa_, fb_ = det.detect_records(imgs[0]), det.detect_records(imgs[1])
+    assert lines["faces"] == f"{len(fa_)} {len(fb_)}" and len(fa_) > 0
+    assert [int(v) for v in lines["box"].split()[:4]] == [int(fa_[0][k]) for k in ("x", "y", "w", "h")]
+    f1, f2 = rec.extractFeature(imgs[0], fa_[0]), rec.extractFeature(imgs[1], fb_[0])
+    assert lines["dim"] == "512 512" and lines["simple"] == "512"
+    assert abs(float(lines["similarity"].split()[0]) - rec.compareFaces(f1, f2)) < 2e-6
+    assert abs(float(lines["self"]) - 1.0) < 1e-5
+    np.testing.assert_allclose([float(v) for v in lines["f1"].split()], f1[:8], atol=2e-6)
+    # reference error behaviour through the shim: bad model path -> loadModel false -> exit code -1
+    bad = subprocess.run([exe, "/nonexistent.onnx", rpath, pa, "120", "160", pb, "120", "160"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "Error loading face detector model" in bad.stderr
