@@ -310,6 +310,12 @@ int fh_resize_u8c3_dev(const uint8_t* src, int sh, int sw, int sstep, uint8_t* d
     });
 }
 int fh_conv_wt_rows(int cout) { return fh::conv_wt_rows(cout); }
+int fh_conv_pack_weights(const float* w_ohwi, int cout, int cin, int ksize, float* dst_packed) {
+    if (!w_ohwi || !dst_packed || cout <= 0 || cin <= 0) return arg_error("fh_conv_pack_weights: bad argument");
+    memset(dst_packed, 0, (size_t)fh::conv_wt_rows(cout) * fh::conv_kpad(ksize * ksize * cin) * sizeof(float));
+    fh::conv_pack_weights(w_ohwi, cout, cin, ksize, dst_packed);
+    return 0;
+}
 int fh_conv_kpad(int ktot) { return fh::conv_kpad(ktot); }
 int fh_conv_forward_dev(const float* in, const float* wt, const float* bias, float* out, int batch, int h, int w, int cin, int cout,
                         int ks, int stride, int kpad, int cfg, void* stream) {

@@ -93,7 +93,7 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
             d.Kpad = conv_kpad(Ktot);
             const int rows = conv_wt_rows(op.Cout);
             std::vector<float> packed((size_t)rows * d.Kpad, 0.f);
-            for (int co = 0; co < op.Cout; ++co) memcpy(&packed[(size_t)co * d.Kpad], &op.weight[(size_t)co * Ktot], (size_t)Ktot * 4);
+            conv_pack_weights(op.weight.data(), op.Cout, op.Cin, op.ks, packed.data());
             d.wt = push(packed.data(), packed.size());
         } else if (op.kind == OpKind::DWCONV) {
             d.wt = push(op.weight.data(), op.weight.size());

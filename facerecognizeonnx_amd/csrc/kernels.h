@@ -39,7 +39,9 @@ struct ConvArgs {
 void launch_conv(const ConvArgs& a, int cfg, hipStream_t s);
 int conv_pick_cfg(long M, int Cout);
 int conv_wt_rows(int Cout);                   // packed weight rows (Cout rounded up to 128)
-size_t conv_slab_floats();                    // size of the stream-K slab workspace
+size_t conv_slab_floats();
+// host: plan-layout weights [Cout][ks*ks][Cin] -> packed [conv_wt_rows(Cout)][conv_kpad(ks*ks*Cin)] (dst pre-zeroed)
+void conv_pack_weights(const float* w, int Cout, int Cin, int ks, float* dst);                    // size of the stream-K slab workspace
 inline int conv_kpad(int Ktot) { return (Ktot + 31) / 32 * 32; }
 
 // --------------------------------------------------------------------------------------------

@@ -142,6 +142,8 @@ FH_API int fh_resize_u8c3_dev(const uint8_t* d_src, int sh, int sw, int sstep, u
 FH_API int fh_conv_forward_dev(const float* d_in, const float* d_wt_packed, const float* d_bias, float* d_out, int batch,
                                int h, int w, int cin, int cout, int ksize, int stride, int kpad, int cfg, void* stream);
 FH_API int fh_conv_wt_rows(int cout);
+/* host: weights [cout][ksize*ksize][cin] (O,H,W,I) -> the kernel's packed image [fh_conv_wt_rows][fh_conv_kpad] */
+FH_API int fh_conv_pack_weights(const float* w_ohwi, int cout, int cin, int ksize, float* dst_packed);
 FH_API int fh_conv_kpad(int ktot);
 
 #ifdef __cplusplus

@@ -12,7 +12,8 @@ L = fa.lib(); L.fh_init(0)
 rng = np.random.default_rng(0)
 x = torch.from_numpy(rng.standard_normal((B, H, W, Cin)).astype(np.float32)).cuda()
 rows, kpad = L.fh_conv_wt_rows(Cout), L.fh_conv_kpad(k * k * Cin)
-wp = np.zeros((rows, kpad), np.float32); wp[:Cout, :k * k * Cin] = rng.standard_normal((Cout, k * k * Cin)) / np.sqrt(k * k * Cin)
+wp = np.zeros((rows, kpad), np.float32); w0 = (rng.standard_normal((Cout, k * k, Cin)) / np.sqrt(k * k * Cin)).astype(np.float32)
+L.fh_conv_pack_weights(w0.ctypes.data, Cout, Cin, k, wp.ctypes.data)
 w = torch.from_numpy(wp).cuda(); b = torch.zeros(Cout, device="cuda")
 Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
 out = torch.zeros((B, Ho, Wo, Cout), device="cuda")

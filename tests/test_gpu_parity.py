@@ -32,12 +32,13 @@ def dev(a):
 
 
 def pack_weights(w):
-    """ONNX [Cout,Cin,k,k] -> packed [rows][Kpad] with k = tap*Cin + ci (kernels.h ConvArgs.wt)."""
+    """ONNX [Cout,Cin,k,k] -> the kernel's packed weight image (layout owned by the library)."""
     cout, cin, k, _ = w.shape
     L = fa.lib()
     rows, kpad = L.fh_conv_wt_rows(cout), L.fh_conv_kpad(k * k * cin)
     out = np.zeros((rows, kpad), np.float32)
-    out[:cout, :k * k * cin] = w.transpose(0, 2, 3, 1).reshape(cout, k * k * cin)
+    ohwi = np.ascontiguousarray(w.transpose(0, 2, 3, 1))
+    assert L.fh_conv_pack_weights(ohwi.ctypes.data, cout, cin, k, out.ctypes.data) == 0
     return out, kpad
 
 
