@@ -225,9 +225,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                 a_mask[i] = mk;
             }
         }
-        const float* w_ptr[BL];
+        // weights: wave-uniform base that advances 128 B per chunk + a constant 32-bit lane offset
+        // (lets the loads use the scalar-base addressing form: no per-chunk vector pointer math)
+        const char* w_base = reinterpret_cast<const char*>(p.wt) + ((size_t)n0 * p.Kpad + (size_t)c_begin * 32) * 4;
+        unsigned w_off[BL];
 #pragma unroll
-        for (int i = 0; i < BL; ++i) w_ptr[i] = p.wt + (size_t)(n0 + lrow + i * RP) * p.Kpad + lqs * 4 + (size_t)c_begin * 32;
+        for (int i = 0; i < BL; ++i) w_off[i] = (unsigned)(((lrow + i * RP) * p.Kpad + lqs * 4) * 4);
 
         const unsigned long long zero_addr = (unsigned long long)p.zeros + (unsigned long long)(lane & 0) ;
         v4f* const dstA = &lds[0][wid * 64];               // + buf*(BM+BN)*8 + i*RP*8; the hardware adds 16*lane
@@ -258,7 +261,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
 #pragma unroll
                 for (int i = 0; i < AL; ++i) { lds_dma16(cur[i], dA + i * RP * 8); cur[i] += 32; }
 #pragma unroll
-                for (int i = 0; i < BL; ++i) { lds_dma16(w_ptr[i], dB + i * RP * 8); w_ptr[i] += 32; }
+                for (int i = 0; i < BL; ++i) lds_dma16(reinterpret_cast<const float*>(w_base + w_off[i]), dB + i * RP * 8);
+                w_base += 128;
                 ld_ci += 32;
                 if (ld_ci >= p.Cin) { ld_ci = 0; ++ld_tap; tap_setup(); }      // wave-uniform branch
                 return;
@@ -282,7 +286,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                 lds_dma16((const float*)sel, dA + i * RP * 8);
             }
 #pragma unroll
-            for (int i = 0; i < BL; ++i) { lds_dma16(w_ptr[i], dB + i * RP * 8); w_ptr[i] += 32; }
+            for (int i = 0; i < BL; ++i) lds_dma16(reinterpret_cast<const float*>(w_base + w_off[i]), dB + i * RP * 8);
+            w_base += 128;
         };
 
         v16f acc[TM][TN];
