@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 CFG_NAMES = ["conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<256,64,4,1>", "conv_igemm_kernel<128,32,4,1>",
-             "conv_igemm_kernel<64,64,2,2>", "dwconv3x3_kernel", "other graph ops"]
+             "conv_igemm_kernel<64,64,2,2>", "dwconv3x3_kernel", "other graph ops", "conv_fixup_kernel"]
 
 
 def parse():
@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--nms-thr", type=float, default=0.4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--cpu-sample-frames", type=int, default=3)
+    ap.add_argument("--cpu-sample-frames", type=int, default=32)
     return ap.parse_args()
 
 
@@ -162,11 +162,11 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    ms, fl, by = (C.c_double * 6)(), (C.c_double * 6)(), (C.c_double * 6)()
-    ln = (C.c_longlong * 6)()
+    ms, fl, by = (C.c_double * 7)(), (C.c_double * 7)(), (C.c_double * 7)()
+    ln = (C.c_longlong * 7)()
     if timing:
         L.fh_timing_enable(0)
-        fa._lib.check(L.fh_timing_collect(ms, fl, by, ln, 6), "fh_timing_collect")
+        fa._lib.check(L.fh_timing_collect(ms, fl, by, ln, 7), "fh_timing_collect")
 
     total_units, max_dt = float(units), dt
     if dist is not None:
@@ -202,15 +202,20 @@ def main():
             if conv:
                 dom = max(conv)
                 tf = dom[1] / (dom[0] * 1e-3) / 1e12
-                allms, allfl = sum(c[0] for c in conv), sum(c[1] for c in conv)
+                allms, allfl = sum(c[0] for c in conv) + ms[6], sum(c[1] for c in conv)   # fix-up time counts against the convs
+                traffic = None
+                tpath = os.path.join(ROOT, "profiles", "traffic.json")     # written by scripts/summarize_profile.py from --pmc runs
+                if os.path.exists(tpath):
+                    tj = json.load(open(tpath))
+                    traffic = tj.get(args.workload, {}).get(CFG_NAMES[dom[3]])
                 out["roofline"] = {"bound": "mfma", "kernel": CFG_NAMES[dom[3]], "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                    "launches": int(dom[2]), "avg_launch_us": 1e3 * dom[0] / dom[2],
                                    "algorithmic_gflop_per_launch": dom[1] / dom[2] / 1e9,
                                    "all_conv_igemm": {"achieved": allfl / (allms * 1e-3) / 1e12,
                                                       "frac": allfl / (allms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                                       "ms_per_step": allms / args.steps},
-                                   "per_kernel_ms_per_step": {CFG_NAMES[i]: ms[i] / args.steps for i in range(6) if ln[i] > 0}}
+                                   "per_kernel_ms_per_step": {CFG_NAMES[i]: ms[i] / args.steps for i in range(7) if ln[i] > 0}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(det_path, rec_path, host, args)
         print(json.dumps(out), flush=True)

@@ -437,7 +437,7 @@ static const float* zero_line() {                      // 8 KiB of zeros: a padd
 size_t conv_slab_floats() { return (size_t)2 * 1280 * 128 * 128; }   // 2 segments x (<= 1280 stream-K workgroups) x largest tile
 
 template <int BM, int BN, int WM, int WN, int OCC>
-static void launch_cfg(ConvArgs a, int resident_per_cu, hipStream_t s) {
+static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t s) {
     const long M = (long)a.B * a.Ho * a.Wo;
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (a.Cout + BN - 1) / BN;
     const int T = tiles_m * tiles_n;
@@ -462,12 +462,17 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, hipStream_t s) {
     }
     if (sk_wgs == 0) { full = T; R = 0; }
     a.sk_full = full;
+    KernelTimer& timer = KernelTimer::get();
+    timer.begin(s);
     if ((a.Cin & 31) == 0)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true>), dim3((unsigned)(full + sk_wgs)), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
     else
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, false>), dim3((unsigned)(full + sk_wgs)), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+    timer.end(s, cfg_tag, a.t_flops, a.t_bytes);
+    if (sk_wgs > 0) timer.begin(s);
     if (sk_wgs > 0)
         hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, WM, WN>), dim3((unsigned)R), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+    if (sk_wgs > 0) timer.end(s, 6, 0.0, 0.0);
 }
 
 void launch_conv(const ConvArgs& a, int cfg, hipStream_t s) {
@@ -475,10 +480,10 @@ void launch_conv(const ConvArgs& a, int cfg, hipStream_t s) {
     if (M <= 0) return;
     if (cfg < 0) cfg = conv_pick_cfg(M, a.Cout);
     switch (cfg) {
-        case 0: launch_cfg<128, 128, 2, 2, 2>(a, 2, s); break;
-        case 1: launch_cfg<256, 64, 4, 1, 2>(a, 2, s); break;
-        case 2: launch_cfg<128, 32, 4, 1, 4>(a, 4, s); break;
-        default: launch_cfg<64, 64, 2, 2, 4>(a, 5, s); break;
+        case 0: launch_cfg<128, 128, 2, 2, 2>(a, 2, 0, s); break;
+        case 1: launch_cfg<256, 64, 4, 1, 2>(a, 2, 1, s); break;
+        case 2: launch_cfg<128, 32, 4, 1, 4>(a, 4, 2, s); break;
+        default: launch_cfg<64, 64, 2, 2, 4>(a, 5, 3, s); break;
     }
 }
 

@@ -14,29 +14,6 @@
 
 namespace fh {
 
-void hip_check(hipError_t e, const char* what);
-#define FH_HIP(x) ::fh::hip_check((x), #x)
-
-// Optional per-launch HIP-event timing of the network kernels (bench.py's roofline leg).
-// Tags: 0..3 = conv_igemm tile configs (kernels.h), 4 = depthwise conv, 5 = other graph ops.
-struct KernelTimer {
-    static constexpr int kTags = 6;
-    bool enabled = false;
-    void begin(hipStream_t s);
-    void end(hipStream_t s, int tag, double flops, double bytes);
-    // synchronises, aggregates elapsed ms / flops / bytes / launches per tag, then resets
-    void collect(double* ms, double* flops, double* bytes, long long* launches);
-    // un-aggregated variant (tuning): one entry per recorded launch, in launch order
-    int collect_ops(double* ms, double* flops, int* tag, int cap);
-    static KernelTimer& get();
-
-  private:
-    struct Rec { hipEvent_t a, b; int tag; double flops, bytes; };
-    std::vector<Rec> recs_;
-    std::vector<hipEvent_t> pool_;
-    hipEvent_t cur_ = nullptr;
-    hipEvent_t take();
-};
 
 struct DevBuf {                // owning hipMalloc buffer
     void* p = nullptr;

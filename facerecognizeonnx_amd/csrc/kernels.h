@@ -4,7 +4,34 @@
 
 #include <cstdint>
 
+#include <vector>
+
 namespace fh {
+
+void hip_check(hipError_t e, const char* what);
+#define FH_HIP(x) ::fh::hip_check((x), #x)
+
+// Optional per-launch HIP-event timing of the network kernels (bench.py's roofline leg).
+// Tags: 0..3 = conv_igemm tile configs, 4 = depthwise conv, 5 = other graph ops, 6 = conv stream-K fix-up.
+struct KernelTimer {
+    static constexpr int kTags = 7;
+    bool enabled = false;
+    void begin(hipStream_t s);
+    void end(hipStream_t s, int tag, double flops, double bytes);
+    // synchronises, aggregates elapsed ms / flops / bytes / launches per tag, then resets
+    void collect(double* ms, double* flops, double* bytes, long long* launches);
+    // un-aggregated variant (tuning): one entry per recorded launch, in launch order
+    int collect_ops(double* ms, double* flops, int* tag, int cap);
+    static KernelTimer& get();
+
+  private:
+    struct Rec { hipEvent_t a, b; int tag; double flops, bytes; };
+    std::vector<Rec> recs_;
+    std::vector<hipEvent_t> pool_;
+    hipEvent_t cur_ = nullptr;
+    hipEvent_t take();
+};
+
 
 // --------------------------------------------------------------------------------------------
 // Dense convolution / FC as implicit GEMM on v_mfma_f32_32x32x2_f32 (conv_mfma.hip)
@@ -32,6 +59,7 @@ struct ConvArgs {
     int oc0[4];
     int oact[3];
     int sk_enable;          // allow the stream-K remainder wave
+    double t_flops, t_bytes; // algorithmic work of this launch (only used by the optional KernelTimer)
     int sk_full, sk_units, sk_q;   // filled in by launch_conv: #plain tiles, remainder K-chunks, chunks per stream-K workgroup
 };
 

@@ -125,7 +125,7 @@ FH_API int fh_gallery_topk_dev(fh_gallery* g, const float* d_queries, int nq, in
 
 /* ---- measurement hooks (bench.py): per-launch HIP-event timing of the network kernels.
  * Tags 0..3 = conv_igemm tile configs (128x128, 256x64, 128x32, 64x64), 4 = depthwise conv,
- * 5 = other graph ops.  fh_timing_collect synchronises, fills 6-entry arrays (elapsed ms,
+ * 5 = other graph ops, 6 = conv stream-K fix-up.  fh_timing_collect synchronises, fills 7-entry arrays (elapsed ms,
  * algorithmic FLOP, algorithmic activation bytes, launches) and resets the counters.
  * fh_*_set_conv_cfg forces one tile config for every dense conv of a handle (-1 = automatic)
  * and switches the stream-K remainder wave on/off (tuning / A-B measurements). */
