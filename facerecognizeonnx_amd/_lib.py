@@ -80,6 +80,8 @@ PROTOTYPES = {
     "fh_det_set_conv_cfg": (_i, [_vp, _i, _i]),
     "fh_rec_set_conv_cfg": (_i, [_vp, _i, _i]),
     "fh_memcpy_d2h": (_i, [_vp, _vp, C.c_size_t]),
+    "fh_det_set_fused_stem": (_i, [_vp, _i]),
+    "fh_rec_set_fused_stem": (_i, [_vp, _i]),
     "fh_resize_u8c3_dev": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "fh_conv_forward_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fh_conv_wt_rows": (_i, [_i]),

@@ -250,12 +250,14 @@ int fh_pipeline_run_dev(fh_det* d, fh_rec* r, const uint8_t* frames, int n, int 
         d->det.detect_dev(frames, n, rows, cols, step, (long)stride, score_thr, nms_thr, d->p_det.as<fh::FaceRec>(), F, d->p_cnt.as<int>(), s);
         fh::launch_select_faces(d->p_det.as<fh::FaceRec>(), d->p_cnt.as<int>(), n, F, F, reinterpret_cast<fh::FaceRec*>(faces), frame_of,
                                 d->p_total.as<int>(), s);
+        // No host round trip between detect and embed: all n*F slots are launched, slots beyond the
+        // device-side face count are emptied by the align kernel (ok = 0) and their embeddings are
+        // never reported.  The one synchronisation is at the end, to return the count.
+        r->rec.embed_faces_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, n * F, emb,
+                               nullptr, s, d->p_total.as<int>());
         int total = 0;
         FH_HIP(hipMemcpyAsync(&total, d->p_total.p, sizeof(int), hipMemcpyDeviceToHost, s));
         FH_HIP(hipStreamSynchronize(s));
-        if (total > 0)
-            r->rec.embed_faces_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, total, emb,
-                                   nullptr, s);
         return total;
     });
 }
@@ -290,6 +292,8 @@ int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k) {
     d->det.net().force_cfg = cfg; d->det.net().sk_enable = stream_k != 0;
     return FH_OK;
 }
+int fh_det_set_fused_stem(fh_det* d, int on) { if (!d) return arg_error("null handle"); d->det.net().fuse_stem = on != 0; return FH_OK; }
+int fh_rec_set_fused_stem(fh_rec* r, int on) { if (!r) return arg_error("null handle"); r->rec.net().fuse_stem = on != 0; return FH_OK; }
 int fh_rec_set_conv_cfg(fh_rec* r, int cfg, int stream_k) {
     if (!r) return arg_error("null handle");
     r->rec.net().force_cfg = cfg; r->rec.net().sk_enable = stream_k != 0;

@@ -102,6 +102,18 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
         if (!op.slope.empty()) { d.slope = push(op.slope.data(), op.slope.size()); d.has_slope = true; }
         if (!op.s2.empty()) { d.s2 = push(op.s2.data(), op.s2.size()); d.t2 = push(op.t2.data(), op.t2.size()); d.has_aff = true; }
     }
+    {   // can the first conv take the u8 image directly?  (3x3, Cin = 3 stored as 4, plain epilogue)
+        const POp& op = plan_.ops[0];
+        stem_ok_ = op.kind == OpKind::CONV && op.in == plan_.input && op.ks == 3 && op.Cin == 4 && op.res < 0 && op.outs.empty() &&
+                   op.Cout % 4 == 0 && op.Cout <= 64 && (op.stride == 1 || op.stride == 2);
+        if (stem_ok_) {
+            std::vector<float> w27((size_t)27 * op.Cout);
+            for (int co = 0; co < op.Cout; ++co)
+                for (int t = 0; t < 9; ++t)
+                    for (int ci = 0; ci < 3; ++ci) w27[(size_t)(t * 3 + ci) * op.Cout + co] = op.weight[((size_t)co * 9 + t) * 4 + ci];
+            dev_[0].w27 = push(w27.data(), w27.size());
+        }
+    }
     params_.ensure(std::max<size_t>(host.size(), 64) * sizeof(float));
     FH_HIP(hipMemcpy(params_.p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     // host copies of the weights are no longer needed
@@ -117,12 +129,32 @@ void Net::reserve(int max_batch) {
     FH_HIP(hipMemset(arena_.p, 0, arena_.bytes));
 }
 
-void Net::run(int batch, hipStream_t s) {
+void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int batch, hipStream_t s) {
+    if (batch <= 0) return;
+    if (batch > cap_) throw std::runtime_error("Net::run_u8: batch exceeds reserved capacity");
+    if (stem_ok_ && fuse_stem) {
+        const POp& op = plan_.ops[0];
+        const DevOp& d = dev_[0];
+        const float* P = params_.as<float>();
+        KernelTimer& timer = KernelTimer::get();
+        timer.begin(s);
+        launch_stem_conv_u8(src, img_stride, srcH, srcW, step, batch, plan_.inH, plan_.inW, op.stride, op.Cout, P + d.w27, P + d.bias,
+                            d.has_slope ? P + d.slope : nullptr, (int)op.act, op.out >= 0 ? tensor_ptr(op.out) : nullptr,
+                            op.out2 >= 0 ? tensor_ptr(op.out2) : nullptr, d.has_aff ? P + d.s2 : nullptr, d.has_aff ? P + d.t2 : nullptr, s);
+        timer.end(s, 5, 2.0 * op.macs * batch, op.bytes * batch);
+        run(batch, s, 1);
+        return;
+    }
+    launch_det_preprocess(src, img_stride, srcH, srcW, step, batch, plan_.inH, plan_.inW, srcH, srcW, input(), s);
+    run(batch, s, 0);
+}
+
+void Net::run(int batch, hipStream_t s, int first_op) {
     if (batch <= 0) return;
     if (batch > cap_) throw std::runtime_error("Net::run: batch exceeds reserved capacity");
     const float* P = params_.as<float>();
     KernelTimer& timer = KernelTimer::get();
-    for (size_t i = 0; i < plan_.ops.size(); ++i) {
+    for (size_t i = (size_t)first_op; i < plan_.ops.size(); ++i) {
         const POp& op = plan_.ops[i];
         const DevOp& d = dev_[i];
         int tag = 5;
@@ -233,8 +265,7 @@ void Detector::run_network_dev(const uint8_t* frames, int n, int rows, int cols,
         launch_resize_u8c3(frames, stride, rows, cols, step, resized_.as<uint8_t>(), (long)newH * newW * 3, newH, newW, newW * 3, n, s);
         src = resized_.as<uint8_t>(); sstride = (long)newH * newW * 3; sstep = newW * 3;
     }
-    launch_det_preprocess(src, sstride, rows, cols, sstep, n, inH, inW, newH, newW, net_.input(), s);
-    net_.run(n, s);
+    net_.run_u8(src, sstride, newH, newW, sstep, n, s);
 }
 
 void Detector::postprocess_dev(int n, float score_thr, float nms_thr, FaceRec* out, int max_out, int* counts, hipStream_t s) {
@@ -273,8 +304,7 @@ void Recognizer::embed_aligned_dev(const uint8_t* crops, int n, float* out, hipS
     net_.reserve(std::min(n, max_chunk));
     for (int off = 0; off < n; off += max_chunk) {
         const int c = std::min(max_chunk, n - off);
-        launch_rec_preprocess(crops + (size_t)off * H * W * 3, c, H, W, net_.input(), s);
-        net_.run(c, s);
+        net_.run_u8(crops + (size_t)off * H * W * 3, (long)H * W * 3, H, W, W * 3, c, s);
         if (raw_out) FH_HIP(hipMemcpyAsync(raw_out + (size_t)off * dim_, net_.output(0), (size_t)c * dim_ * sizeof(float), hipMemcpyDeviceToDevice, s));
         launch_l2_normalize(net_.output(0), out + (size_t)off * dim_, c, dim_, s);
     }
@@ -282,19 +312,19 @@ void Recognizer::embed_aligned_dev(const uint8_t* crops, int n, float* out, hipS
 }
 
 void Recognizer::align_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces,
-                           const int* frame_of, int n, uint8_t* crops, int* ok, hipStream_t s) {
-    launch_align(frames, stride, rows, cols, step, faces, frame_of, n, net_.in_h(), net_.in_w(), crops, ok, s);
+                           const int* frame_of, int n, uint8_t* crops, int* ok, hipStream_t s, const int* live) {
+    launch_align(frames, stride, rows, cols, step, faces, frame_of, n, net_.in_h(), net_.in_w(), crops, ok, s, live);
     FH_HIP(hipGetLastError());
 }
 
 void Recognizer::embed_faces_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces,
-                                 const int* frame_of, int n, float* out, int* ok, hipStream_t s) {
+                                 const int* frame_of, int n, float* out, int* ok, hipStream_t s, const int* live) {
     if (n <= 0) return;
     const size_t crop = (size_t)net_.in_h() * net_.in_w() * 3;
     crops_.ensure((size_t)n * crop);
     ok_.ensure((size_t)n * sizeof(int));
     int* okp = ok ? ok : ok_.as<int>();
-    align_dev(frames, rows, cols, step, stride, faces, frame_of, n, crops_.as<uint8_t>(), okp, s);
+    align_dev(frames, rows, cols, step, stride, faces, frame_of, n, crops_.as<uint8_t>(), okp, s, live);
     embed_aligned_dev(crops_.as<uint8_t>(), n, out, s);
 }
 

@@ -33,7 +33,11 @@ class Net {
     void reserve(int max_batch);                          // arena + split-K slabs for this batch
     float* input() const { return arena_.as<float>() + plan_.tensors[plan_.input].offset * (size_t)cap_; }
     float* output(int i) const { return tensor_ptr(plan_.outputs[i].tensor); }
-    void run(int batch, hipStream_t s);
+    void run(int batch, hipStream_t s, int first_op = 0);
+    // preprocess (+ first conv when it can be fused) straight from BGR u8 images, then the rest of the graph.
+    // srcH x srcW = pasted image (<= net input; the remainder is the zero letterbox canvas)
+    void run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int batch, hipStream_t s);
+    bool fuse_stem = true;                                // tuning / test hook: keep the preprocessed input tensor
     const Plan& plan() const { return plan_; }
     int in_h() const { return plan_.inH; }
     int in_w() const { return plan_.inW; }
@@ -45,6 +49,7 @@ class Net {
     struct DevOp {
         size_t wt = 0, bias = 0, slope = 0, s2 = 0, t2 = 0;   // float offsets into params_
         bool has_slope = false, has_aff = false;
+        size_t w27 = 0;                                       // stem layout [27][Cout] (op 0 only)
         int Kpad = 0;
     };
     float* tensor_ptr(int t) const { return arena_.as<float>() + plan_.tensors[t].offset * (size_t)cap_; }
@@ -52,6 +57,7 @@ class Net {
     std::vector<DevOp> dev_;
     DevBuf params_, arena_, partial_;
     int cap_ = 0;
+    bool stem_ok_ = false;
 };
 
 class Detector {
@@ -88,9 +94,9 @@ class Recognizer {
     void embed_aligned_dev(const uint8_t* crops, int n, float* out, hipStream_t s, float* raw_out = nullptr);
     // alignFace + embed: faces[n] (device) on frames; ok[n] (device, may be null) 1/2 = produced, 0 = empty
     void embed_faces_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces,
-                         const int* frame_of, int n, float* out, int* ok, hipStream_t s);
+                         const int* frame_of, int n, float* out, int* ok, hipStream_t s, const int* live = nullptr);
     void align_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces, const int* frame_of,
-                   int n, uint8_t* crops, int* ok, hipStream_t s);
+                   int n, uint8_t* crops, int* ok, hipStream_t s, const int* live = nullptr);
     void resize_embed_dev(const uint8_t* frames, int n, int rows, int cols, int step, long stride, float* out, hipStream_t s);
     int max_chunk = 256;                                 // faces per network pass
 

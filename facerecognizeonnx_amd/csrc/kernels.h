@@ -97,6 +97,11 @@ void launch_det_preprocess(const uint8_t* frames, long img_stride, int rows, int
                            int inH, int inW, int newH, int newW, float* out, hipStream_t s);
 // FaceRecognizer::preprocess (src/face_recognizer.cpp:135-150) on aligned crops → NHWC4
 void launch_rec_preprocess(const uint8_t* crops, int n, int H, int W, float* out, hipStream_t s);
+// preprocess fused into the graph's first Conv 3x3 (Cin = 3): u8 BGR image -> [B,Ho,Wo,Cout] fp32.
+// w27 = [27][Cout] with k = (ky*3+kx)*3 + ci (ci in RGB order); act as fh::Act.
+void launch_stem_conv_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int B, int inH, int inW, int stride,
+                         int Cout, const float* w27, const float* bias, const float* slope, int act, float* out1, float* out2,
+                         const float* s2, const float* t2, hipStream_t s);
 
 struct DecodeArgs {
     const float* score[3];  // per stride [B, gh*gw*2]
@@ -121,7 +126,8 @@ void launch_sort_nms(const FaceRec* cand, unsigned long long* keys, const int* c
 // FaceRecognizer::alignFace (src/face_recognizer.cpp:93-133): similarity estimate + warpAffine
 //   faces[n] with frame index frame_of[n]; writes crops [n,112,112,3] BGR u8 and ok[n].
 void launch_align(const uint8_t* frames, long img_stride, int rows, int cols, int step, const FaceRec* faces,
-                  const int* frame_of, int n, int outH, int outW, uint8_t* crops, int* ok, hipStream_t s);
+                  const int* frame_of, int n, int outH, int outW, uint8_t* crops, int* ok, hipStream_t s,
+                  const int* live = nullptr);   // live[0] (device) = number of valid faces, slots beyond it are emptied
 void launch_resize_u8c3(const uint8_t* src, long src_stride, int sh, int sw, int sstep, uint8_t* dst, long dst_stride,
                         int dh, int dw, int dstep, int n, hipStream_t s);
 

@@ -3,6 +3,7 @@
 // stand-alone activations, Add and nearest 2x up-sampling.  All tensors are channels-last fp32,
 // every lane moves 16 bytes (4 channels) per access so a wave covers whole 128-byte lines.
 // These are the ONNX nodes ORT runs inside session_->Run (reference src/face_detector.cpp:179-183).
+// Also here: the first convolution fused with the u8 preprocess (stem_conv_u8_kernel).
 #include <hip/hip_runtime.h>
 
 #include "kernels.h"
@@ -140,5 +141,105 @@ void launch_upsample2x(const float* in, float* out, int B, int H, int W, int C, 
     const long total = (long)B * 4 * H * W * C;
     hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, B, H, W, C);
 }
+
+
+// ------------------------------------------------------------------------------------------
+// First convolution fused with the image preprocess (FaceDetector::preprocess
+// src/face_detector.cpp:120-136 / FaceRecognizer::preprocess src/face_recognizer.cpp:135-150 +
+// the graph's first Conv 3x3, Cin = 3): reads the BGR u8 image once (1 byte per sample instead
+// of a 4-byte float written and read back), normalises into an LDS tile and runs the 27-tap
+// stencil on the vector ALU.  K = 27 is far too thin for the matrix cores and the layer is bound
+// by its output write anyway.  Letterbox area (inside the net input, outside the pasted image)
+// = u8 0 = -0.99609375 after normalisation; outside the net input = the conv's zero padding.
+// Thread = 4 output channels x (TILE*TILE*4/Cout... ) pixels; weights live in registers.
+// ------------------------------------------------------------------------------------------
+constexpr int STEM_TILE = 16;
+
+template <int STRIDE>
+__global__ __launch_bounds__(256) void stem_conv_u8_kernel(const uint8_t* __restrict__ src, long img_stride, int srcH, int srcW, int step,
+                                                           int inH, int inW, int Ho, int Wo, int Cout, const float* __restrict__ w27,
+                                                           const float* __restrict__ bias, const float* __restrict__ slope, int act,
+                                                           float* __restrict__ out1, float* __restrict__ out2,
+                                                           const float* __restrict__ s2, const float* __restrict__ t2, int ntiles) {
+    constexpr int IT = (STEM_TILE - 1) * STRIDE + 3;                 // input tile edge
+    __shared__ float tile[IT * IT * 3];
+    const int tid = threadIdx.x;
+    const int tiles_x = (Wo + STEM_TILE - 1) / STEM_TILE, tiles_y = (Ho + STEM_TILE - 1) / STEM_TILE;
+    const int G = Cout >> 2;                                         // channel groups of 4
+    const int c4 = tid % G;
+    const int pix_per_pass = 256 / G;
+    v4f w[27];                                                       // [tap][ci] for this thread's 4 channels, loaded ONCE per block
+#pragma unroll
+    for (int k = 0; k < 27; ++k) w[k] = *reinterpret_cast<const v4f*>(w27 + (size_t)k * Cout + c4 * 4);
+    const v4f b4 = *reinterpret_cast<const v4f*>(bias + c4 * 4);
+    v4f sl = {0.f, 0.f, 0.f, 0.f}, sc2 = {0.f, 0.f, 0.f, 0.f}, sh2 = {0.f, 0.f, 0.f, 0.f};
+    if (slope) sl = *reinterpret_cast<const v4f*>(slope + c4 * 4);
+    if (out2) { sc2 = *reinterpret_cast<const v4f*>(s2 + c4 * 4); sh2 = *reinterpret_cast<const v4f*>(t2 + c4 * 4); }
+    // persistent blocks: each walks over many tiles, so the 27 weight vectors are fetched once
+    for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int b = tl / (tiles_x * tiles_y);
+        const int t = tl - b * tiles_x * tiles_y;
+        const int oy0 = (t / tiles_x) * STEM_TILE, ox0 = (t % tiles_x) * STEM_TILE;
+        const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+        const uint8_t* img = src + (size_t)b * img_stride;
+        __syncthreads();                                             // previous tile fully consumed
+        for (int i = tid; i < IT * IT; i += 256) {
+            const int ty = i / IT, tx = i - ty * IT;
+            const int iy = iy0 + ty, ix = ix0 + tx;
+            float r = 0.f, g = 0.f, bl = 0.f;                        // conv zero padding
+            if ((unsigned)iy < (unsigned)inH && (unsigned)ix < (unsigned)inW) {
+                float vb = 0.f, vg = 0.f, vr = 0.f;                  // letterbox canvas = u8 zeros
+                if (iy < srcH && ix < srcW) {
+                    const uint8_t* p = img + (size_t)iy * step + (size_t)ix * 3;
+                    vb = (float)p[0]; vg = (float)p[1]; vr = (float)p[2];
+                }
+                r = (vr - 127.5f) / 128.0f; g = (vg - 127.5f) / 128.0f; bl = (vb - 127.5f) / 128.0f;
+            }
+            tile[i * 3 + 0] = r; tile[i * 3 + 1] = g; tile[i * 3 + 2] = bl;   // RGB order = graph channel order
+        }
+        __syncthreads();
+        if (tid >= G * pix_per_pass) continue;
+        for (int p = tid / G; p < STEM_TILE * STEM_TILE; p += pix_per_pass) {
+            const int py = p / STEM_TILE, px = p - py * STEM_TILE;
+            const int oy = oy0 + py, ox = ox0 + px;
+            if (oy >= Ho || ox >= Wo) continue;
+            v4f acc = b4;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float* tp = tile + ((py * STRIDE + ky) * IT + px * STRIDE + kx) * 3;
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) acc += w[(ky * 3 + kx) * 3 + ci] * tp[ci];
+                }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[e];
+                if (act == 1) v = v > 0.f ? v : 0.f;
+                else if (act == 2) v = v >= 0.f ? v : v * sl[e];
+                else if (act == 3) v = 1.0f / (1.0f + expf(-v));
+                acc[e] = v;
+            }
+            const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * Cout + c4 * 4;
+            if (out1) *reinterpret_cast<v4f*>(out1 + o) = acc;
+            if (out2) *reinterpret_cast<v4f*>(out2 + o) = acc * sc2 + sh2;
+        }
+    }
+}
+
+void launch_stem_conv_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int B, int inH, int inW, int stride,
+                         int Cout, const float* w27, const float* bias, const float* slope, int act, float* out1, float* out2,
+                         const float* s2, const float* t2, hipStream_t s) {
+    const int Ho = (inH + 2 - 3) / stride + 1, Wo = (inW + 2 - 3) / stride + 1;
+    const int ntiles = B * ((Wo + STEM_TILE - 1) / STEM_TILE) * ((Ho + STEM_TILE - 1) / STEM_TILE);
+    const int blocks = ntiles < 256 * 8 ? ntiles : 256 * 8;
+    if (stride == 1)
+        hipLaunchKernelGGL(stem_conv_u8_kernel<1>, dim3(blocks), dim3(256), 0, s, src, img_stride, srcH, srcW, step, inH, inW, Ho, Wo, Cout,
+                           w27, bias, slope, act, out1, out2, s2, t2, ntiles);
+    else
+        hipLaunchKernelGGL(stem_conv_u8_kernel<2>, dim3(blocks), dim3(256), 0, s, src, img_stride, srcH, srcW, step, inH, inW, Ho, Wo, Cout,
+                           w27, bias, slope, act, out1, out2, s2, t2, ntiles);
+}
+
 
 }  // namespace fh

@@ -134,6 +134,10 @@ FH_API int fh_timing_collect(double* ms, double* flops, double* bytes, long long
 FH_API int fh_timing_collect_ops(double* ms, double* flops, int* tag, int cap);   /* per launch, in order */
 FH_API int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k);
 FH_API int fh_rec_set_conv_cfg(fh_rec* r, int cfg, int stream_k);
+/* on (default): the u8 preprocess is fused into the first convolution and the preprocessed input tensor is
+ * never materialised; off: separate preprocess kernel (needed for fh_det_input_dev). */
+FH_API int fh_det_set_fused_stem(fh_det* d, int on);
+FH_API int fh_rec_set_fused_stem(fh_rec* r, int on);
 
 /* ---- single kernels exposed for parity tests and micro-benchmarks (device pointers). */
 FH_API int fh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);   /* synchronous */

@@ -79,6 +79,7 @@ def test_conv_layer_matches_oracle(B, H, W, Cin, Cout, k, stride, cfg):
 def test_det_preprocess_bit_exact(models_dir):
     det = fa.FaceDetector()
     assert det.loadModel(util.tiny_scrfd(models_dir, hw=128))
+    assert fa.lib().fh_det_set_fused_stem(det.handle, 0) == 0       # materialise the preprocessed input tensor
     for rows, cols in ((128, 128), (96, 128), (200, 150), (64, 50)):
         img = util.frames_u8(1, rows, cols, seed=rows, smooth=True)[0]
         ref, scale = oracle.det_preprocess(img, 128, 128)
@@ -141,6 +142,21 @@ def test_scrfd_network_and_postprocess(models_dir):
             assert cnt[b] == len(ref) and (len(ref) > 0 or thr > 0.5), (thr, nms, cnt[b], len(ref))
             k = min(len(ref), max_pf)
             assert rec[b, :k].tobytes() == ref[:k].tobytes(), (thr, nms, b)
+
+
+def test_fused_stem_equals_separate_preprocess(models_dir):
+    """The u8 -> first-conv fusion must not change results beyond fp32 summation order (letterboxed input included)."""
+    det = fa.FaceDetector()
+    assert det.loadModel(util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0))
+    img = util.frames_u8(1, 90, 128, seed=3, smooth=True)
+    d = dev(img)
+    outs = []
+    for fused in (1, 0):
+        assert fa.lib().fh_det_set_fused_stem(det.handle, fused) == 0
+        assert fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), 1, 90, 128, 384, 90 * 384, 0) == 1
+        outs.append(_det_outputs(det, 1))
+    for a, b in zip(*outs):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5)
 
 
 def test_detect_host_api_matches_oracle_end_to_end(models_dir):
