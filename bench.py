@@ -49,6 +49,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
+    ap.add_argument("--gallery", type=int, default=0, help="config C4/C5: also match every embedding against a gallery of this many "
+                    "512-d rows (row-sharded over the ranks; per-rank top-k all-gathered and merged)")
+    ap.add_argument("--topk", type=int, default=16)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo only to rehearse the N>1 code path")
+    ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -92,12 +97,18 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.all_ranks_on_device0:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.dist_backend)
+    cdev = torch.device("cuda", local) if args.dist_backend == "nccl" else torch.device("cpu")   # where collectives run
 
     import facerecognizeonnx_amd as fa
     from facerecognizeonnx_amd.synth import models
@@ -145,6 +156,33 @@ def main():
                 return fa.pipeline_run_dev(det, rec, data.data_ptr(), B, 640, 640, F, faces.data_ptr(), frame_of.data_ptr(),
                                            emb.data_ptr(), args.score_thr, args.nms_thr, stream)
 
+    if args.gallery > 0 and args.workload != "detect":
+        from facerecognizeonnx_amd import distributed as fd
+        gb, ge = fd.gallery_shard_base(args.gallery, rank, world)
+        grng = torch.Generator(device="cuda"); grng.manual_seed(4 + rank)
+        gal = torch.randn((ge - gb, 512), device="cuda", generator=grng)
+        gal /= gal.norm(dim=1, keepdim=True)
+        gallery = fa.Gallery(512)
+        gallery.upload(gal.data_ptr(), ge - gb, True, gb)
+        del gal
+        nq = emb.shape[0]
+        k = args.topk
+        sc = torch.zeros((nq * world, k), device="cuda"); ix = torch.zeros((nq * world, k), dtype=torch.int32, device="cuda")
+        inner = step
+
+        def step():                                   # noqa: F811
+            n = inner()
+            if world > 1:                             # every rank scores ALL queries against its own gallery shard
+                q = fd.allgather_queries(emb.to(cdev)).to("cuda")
+            else:
+                q = emb
+            for off in range(0, q.shape[0], 256):
+                m = min(256, q.shape[0] - off)
+                gallery.topk_dev(q[off:off + m].data_ptr(), m, k, sc[off:off + m].data_ptr(), ix[off:off + m].data_ptr(), stream)
+            if world > 1:
+                fd.allgather_topk(sc.to(cdev), ix.to(cdev), k)
+            return n
+
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -170,9 +208,9 @@ def main():
 
     total_units, max_dt = float(units), dt
     if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        u = torch.tensor([float(units)], device="cuda", dtype=torch.float64)
+        u = torch.tensor([float(units)], device=cdev, dtype=torch.float64)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         max_dt, total_units = float(t.item()), float(u.item())
 
@@ -195,7 +233,9 @@ def main():
                        "frames_per_gpu": B, "faces_per_frame": F, "faces_per_step_rank0": per_step_faces,
                        "score_thr": args.score_thr, "nms_thr": args.nms_thr,
                        "weights": "synthetic seeded (det seed 100, rec seed 200)",
-                       "parallelism": f"frame-sharded x{world}, no data-path collective"},
+                       "gallery_rows": args.gallery, "topk": args.topk if args.gallery else 0,
+                       "parallelism": f"frame-sharded x{world}, " + ("gallery row-sharded, all-gather of queries + per-rank top-k"
+                                                                     if args.gallery and world > 1 else "no data-path collective")},
         }
         if timing:
             conv = [(ms[i], fl[i], ln[i], i) for i in range(4) if ln[i] > 0]

@@ -37,8 +37,13 @@ ms = (C.c_double * cap)(); fl = (C.c_double * cap)(); tg = (C.c_int * cap)()
 n = L.fh_timing_collect_ops(ms, fl, tg, cap)
 per = n // R
 tot = 0
+oi = 0
 for i in range(per):
     t = np.median([ms[r * per + i] for r in range(R)])
     tot += t
-    print(f"{t*1e3:9.1f} us  {fl[i]/t/1e9 if t>0 else 0:7.1f} TF/s  cfg{tg[i]}  {ops[i] if i < len(ops) else ''}")
+    if tg[i] == 6:
+        print(f"{t*1e3:9.1f} us             fix-up")
+        continue
+    print(f"{t*1e3:9.1f} us  {fl[i]/t/1e9 if t>0 else 0:7.1f} TF/s  cfg{tg[i]}  {ops[oi] if oi < len(ops) else ''}")
+    oi += 1
 print(f"total {tot:.3f} ms for batch {B}; {sum(fl[i] for i in range(per))/tot/1e9:.1f} TF/s overall")
