@@ -380,3 +380,28 @@ def test_cpp_shim_matches_python_api(models_dir, tmp_path):
     # reference error behaviour through the shim: bad model path -> loadModel false -> exit code -1
     bad = subprocess.run([exe, "/nonexistent.onnx", rpath, pa, "120", "160", pb, "120", "160"], capture_output=True, text=True)
     assert bad.returncode != 0 and "Error loading face detector model" in bad.stderr
+
+
+def test_streamk_is_deterministic_and_matches_plain_tiles():
+    """Stream-K remainder wave + slab fix-up: bit-identical from run to run, and equal to the plain one-tile-per-
+    workgroup schedule up to fp32 summation order (K is cut at different places)."""
+    from facerecognizeonnx_amd.synth import models
+    path = models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
+    rec = fa.FaceRecognizer()
+    assert rec.loadModel(path)
+    n = 96                                                  # ragged: no stage has a whole number of tile rounds
+    crops = dev(util.frames_u8(n, 112, 112, seed=12))
+    res = {}
+    for mode in (1, 0, 1, 1):
+        assert fa.lib().fh_rec_set_conv_cfg(rec.handle, -1, mode) == 0
+        raw = torch.zeros((n, 512), device="cuda"); out = torch.zeros((n, 512), device="cuda")
+        assert rec.embed_aligned_dev(crops.data_ptr(), n, out.data_ptr(), raw.data_ptr()) == n
+        torch.cuda.synchronize()
+        r = raw.cpu().numpy()
+        assert np.isfinite(r).all()
+        if mode in res:
+            assert np.array_equal(r, res[mode])
+        res[mode] = r
+    a, b = res[1].astype(np.float64), res[0].astype(np.float64)
+    cos = (a * b).sum(1) / np.linalg.norm(a, axis=1) / np.linalg.norm(b, axis=1)
+    assert (1.0 - cos).max() < 1e-6, (1.0 - cos).max()             # different K cut points: fp32 rounding only
