@@ -74,7 +74,7 @@ struct Tile {
 // C/D map of the 32x32 MFMA: column (= pixel here) = lane & 31, row (= channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0,
-                                              int wm, int wn, int lane) {
+                                              int wm, int wn, int lane, int only_i = -1, int only_j = -1) {
     using TL = Tile<BM, BN, WM, WN>;
     const int fr = lane & 31, fh2 = lane >> 5;
     const int HoWo = p.Ho * p.Wo;
@@ -87,9 +87,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
 #pragma unroll
         for (int i = 0; i < TL::TM; ++i) {
             const int m = m0 + (wm * TL::TM + i) * 32 + fr;
-            if (m >= M) continue;
+            if (m >= M || (only_i >= 0 && i != only_i)) continue;
 #pragma unroll
             for (int j = 0; j < TL::TN; ++j) {
+                if (only_j >= 0 && j != only_j) continue;
                 const int cb = n0 + (wn * TL::TN + j) * 32 + 4 * fh2;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -107,7 +108,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
 #pragma unroll
     for (int i = 0; i < TL::TM; ++i) {
         const int m = m0 + (wm * TL::TM + i) * 32 + fr;
-        if (m >= M) continue;
+        if (m >= M || (only_i >= 0 && i != only_i)) continue;
         const size_t row = (size_t)m * p.Cout;
         size_t rrow = row;
         if (p.res_mode == (int)ResMode::UP2X) {
@@ -117,6 +118,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
         }
 #pragma unroll
         for (int j = 0; j < TL::TN; ++j) {
+            if (only_j >= 0 && j != only_j) continue;
             const int cb = n0 + (wn * TL::TN + j) * 32 + 4 * fh2;
             if (vec) {
                 v4f r4[4];
@@ -357,14 +359,18 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
     }
 }
 
-// Sums the slabs of one stream-K tile in K order and applies the epilogue.
+// Sums the slabs of one stream-K tile in K order and applies the epilogue.  One workgroup per
+// (tile, 32x32 accumulator block of each wave): TM*TN times more workgroups than tiles, because this
+// kernel is pure streaming and R < #CUs*2 tiles alone would leave most of the chip's load queues empty.
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs p, const int tiles_n, const int chunks) {
     using TL = Tile<BM, BN, WM, WN>;
     constexpr int TM = TL::TM, TN = TL::TN;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;
-    const int r = blockIdx.x;                           // remainder tile index
+    const int r = blockIdx.x / (TM * TN);               // remainder tile index
+    const int sub = blockIdx.x - r * (TM * TN);
+    const int si = sub / TN, sj = sub - si * TN;
     const int tile = p.sk_full + r;
     const int ub = r * chunks, ue = ub + chunks;        // this tile's unit range
     const int w_first = ub / p.sk_q, w_last = (ue - 1) / p.sk_q;
@@ -375,22 +381,26 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    v16f sum;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sum[e] = 0.f;
     for (int w = w_first; w <= w_last; ++w) {
         const int seg = (w * p.sk_q >= ub) ? 0 : 1;     // a workgroup's 2nd segment is the tile it spills into
         const float* __restrict__ slab = p.slabs + ((size_t)w * 2 + seg) * TL::SLAB;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int g = 0; g < 4; ++g) {
+            const v4f v = *reinterpret_cast<const v4f*>(slab + ((size_t)((si * TN + sj) * 4 + g) * TL::T + tid) * 4);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const v4f v = *reinterpret_cast<const v4f*>(slab + ((size_t)((i * TN + j) * 4 + g) * TL::T + tid) * 4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[i][j][4 * g + c] += v[c];
-                }
+            for (int c = 0; c < 4; ++c) sum[4 * g + c] += v[c];
+        }
     }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            if (i == si && j == sj) acc[i][j] = sum;
     const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
-    conv_epilogue<BM, BN, WM, WN>(p, acc, tile_m * BM, tile_n * BN, wm, wn, lane);
+    conv_epilogue<BM, BN, WM, WN>(p, acc, tile_m * BM, tile_n * BN, wm, wn, lane, si, sj);
 }
 
 int conv_wt_rows(int Cout) { return (Cout + 127) / 128 * 128; }
@@ -471,7 +481,7 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
     timer.end(s, cfg_tag, a.t_flops, a.t_bytes);
     if (sk_wgs > 0) timer.begin(s);
     if (sk_wgs > 0)
-        hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, WM, WN>), dim3((unsigned)R), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+        hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, WM, WN>), dim3((unsigned)(R * (BM / WM / 32) * (BN / WN / 32))), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
     if (sk_wgs > 0) timer.end(s, 6, 0.0, 0.0);
 }
 
