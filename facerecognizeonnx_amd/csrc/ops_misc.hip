@@ -25,12 +25,66 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
     return v;
 }
 
-// Depthwise 3x3 (+bias +ReLU).  One thread = 4 channels x a strip of STRIP output pixels along x:
-// the 3 x (STRIP*stride + 2) input float4s are loaded once and reused across the strip (4.5
-// instead of 9 loads per output at stride 1), weights stay in registers.  Lanes run over the
-// channel groups first, so a wave's loads cover whole 64..128-byte pixel rows.
+// Depthwise 3x3 (+bias +ReLU).  One thread = 4 channels x a VERTICAL strip of STRIP output pixels:
+// the (STRIP*stride + 2) x 3 input float4s are loaded once and reused down the strip (4.5 instead
+// of 9 loads per output at stride 1), weights stay in registers.  Lanes run over the channel groups
+// and then over x, so every load / store instruction of a wave touches one contiguous run of pixels
+// (full 128-byte lines); a horizontal strip would scatter each instruction over 16 half-used lines.
 template <int STRIDE, int STRIP>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int B, int H, int W, int C, int Ho, int Wo, int act) {
+    constexpr int ROWS = (STRIP - 1) * STRIDE + 3;
+    const int C4 = C >> 2;
+    const int strips = (Ho + STRIP - 1) / STRIP;
+    const long total = (long)B * strips * Wo * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        long r = idx / C4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int sy = (int)(r % strips);
+        const int n = (int)(r / strips);
+        const int oy0 = sy * STRIP;
+        v4f wk[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const v4f*>(w + t * C + c4 * 4);
+        const v4f b4 = *reinterpret_cast<const v4f*>(bias + c4 * 4);
+        v4f acc[STRIP];
+#pragma unroll
+        for (int o = 0; o < STRIP; ++o) acc[o] = b4;
+        const int iy0 = oy0 * STRIDE - 1, ix0 = ox * STRIDE - 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ix0 + kx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const float* colp = in + ((size_t)n * H * W + ix) * C + c4 * 4;
+            v4f x[ROWS];
+#pragma unroll
+            for (int ridx = 0; ridx < ROWS; ++ridx) {
+                const int iy = iy0 + ridx;
+                x[ridx] = (unsigned)iy < (unsigned)H ? *reinterpret_cast<const v4f*>(colp + (size_t)iy * W * C) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int o = 0; o < STRIP; ++o)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) acc[o] += x[o * STRIDE + ky] * wk[ky * 3 + kx];
+        }
+#pragma unroll
+        for (int o = 0; o < STRIP; ++o) {
+            const int oy = oy0 + o;
+            if (oy >= Ho) break;
+            v4f v = acc[o];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act1(v[e], act, 0.f);
+            *reinterpret_cast<v4f*>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4) = v;
+        }
+    }
+}
+
+// Horizontal-strip variant (strip along x): better for stride 2, where a vertical strip would make every
+// wave instruction skip every other pixel.
+template <int STRIDE, int STRIP>
+__global__ __launch_bounds__(256) void dwconv3x3_hstrip_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         int B, int H, int W, int C, int Ho, int Wo, int act) {
     constexpr int COLS = (STRIP - 1) * STRIDE + 3;
@@ -84,11 +138,13 @@ void launch_dwconv3x3(const float* in, const float* w9c, const float* bias, floa
                       int stride, int act, hipStream_t s) {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     constexpr int STRIP = 4;
-    const long total = (long)B * Ho * ((Wo + STRIP - 1) / STRIP) * (C / 4);
-    if (stride == 1)
+    if (stride == 1) {
+        const long total = (long)B * ((Ho + STRIP - 1) / STRIP) * Wo * (C / 4);
         hipLaunchKernelGGL((dwconv3x3_kernel<1, STRIP>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo, act);
-    else
-        hipLaunchKernelGGL((dwconv3x3_kernel<2, STRIP>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo, act);
+    } else {
+        const long total = (long)B * Ho * ((Wo + STRIP - 1) / STRIP) * (C / 4);
+        hipLaunchKernelGGL((dwconv3x3_hstrip_kernel<2, STRIP>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo, act);
+    }
 }
 
 // generic per-channel pass, scalar channel indexing (C need not be a multiple of 4)
