@@ -82,7 +82,7 @@ if os.path.exists(bj):
     bench = open(bj).read().strip()
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
     f.write(f"# rocprofv3 summary {tag} — `python3 bench.py --steps 5 --warmup 2` ({workload})\n\n")
-    f.write("`rocprofv3 --kernel-trace --stats` (7 steps incl. warm-up; the profiled run is slower than an un-profiled one):\n\n")
+    f.write("`rocprofv3 --kernel-trace --stats` (all steps of the run: warm-up + timed + instrumented; a profiled run is slower than an un-profiled one):\n\n")
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows[:16]:
         f.write(f"| {short(r['Name'])} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |\n")
