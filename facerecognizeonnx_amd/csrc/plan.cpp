@@ -78,6 +78,123 @@ struct Val {
 
 Plan build_plan(const OnnxModel& m, int inH, int inW) {
     if (m.inputs.size() != 1) fail("expected exactly one graph input");
+    // ---------------------------------------------------------------- 0. shape / constant pre-pass
+    // Exports with dynamic axes (the public det_500m.onnx has H and W dynamic) compute Resize sizes and
+    // Reshape shapes with small integer sub-graphs (Shape, Gather, Slice, Concat, Unsqueeze, Cast,
+    // Mul, Div, ...).  With the input size fixed at load time they are constants: fold them here, in
+    // file order (ONNX files are topologically sorted), together with the C/H/W of every 4-D value.
+    struct Dim { int c = 0, h = 0, w = 0; };
+    std::map<std::string, Dim> dims;
+    std::map<std::string, std::vector<double>> cvals;
+    std::set<std::string> shape_nodes;                    // outputs of folded nodes (never tensors)
+    auto get_const = [&](const std::string& name, std::vector<double>& out) -> bool {
+        auto it = cvals.find(name);
+        if (it != cvals.end()) { out = it->second; return true; }
+        auto ii = m.inits.find(name);
+        if (ii == m.inits.end() || ii->second.numel() > 64) return false;
+        out.clear();
+        if (!ii->second.i.empty()) out.assign(ii->second.i.begin(), ii->second.i.end());
+        else out.assign(ii->second.f.begin(), ii->second.f.end());
+        return true;
+    };
+    dims[m.inputs[0].name] = Dim{3, inH, inW};
+    for (const auto& n : m.nodes) {
+        if (n.outputs.empty()) continue;
+        const std::string& out = n.outputs[0];
+        auto in_dim = [&](size_t k) -> const Dim* {
+            if (k >= n.inputs.size()) return nullptr;
+            auto it = dims.find(n.inputs[k]);
+            return it == dims.end() ? nullptr : &it->second;
+        };
+        std::vector<double> a, b;
+        if (n.op == "Conv") {
+            const Dim* d = in_dim(0);
+            auto wi = m.inits.find(n.inputs.size() > 1 ? n.inputs[1] : "");
+            if (d && wi != m.inits.end() && wi->second.dims.size() == 4) {
+                const int k = (int)wi->second.dims[2];
+                auto st = n.attr_ints("strides"); auto pd = n.attr_ints("pads");
+                const int s_ = st.empty() ? 1 : (int)st[0], p_ = pd.empty() ? 0 : (int)pd[0];
+                dims[out] = Dim{(int)wi->second.dims[0], (d->h + 2 * p_ - k) / s_ + 1, (d->w + 2 * p_ - k) / s_ + 1};
+            }
+        } else if (n.op == "Resize" || n.op == "Upsample") {
+            const Dim* d = in_dim(0);
+            if (d) {
+                Dim o = *d;
+                bool ok = false;
+                if (n.op == "Upsample") { if (get_const(n.inputs.at(1), a) && a.size() == 4) { o.h = (int)std::floor(d->h * a[2]); o.w = (int)std::floor(d->w * a[3]); ok = true; } }
+                else {
+                    if (n.inputs.size() > 3 && !n.inputs[3].empty() && get_const(n.inputs[3], a) && a.size() == 4) { o.h = (int)a[2]; o.w = (int)a[3]; ok = true; }
+                    else if (n.inputs.size() > 2 && !n.inputs[2].empty() && get_const(n.inputs[2], a) && a.size() == 4) { o.h = (int)std::floor(d->h * a[2]); o.w = (int)std::floor(d->w * a[3]); ok = true; }
+                    else if (n.inputs.size() == 2 && get_const(n.inputs[1], a) && a.size() == 4) { o.h = (int)std::floor(d->h * a[2]); o.w = (int)std::floor(d->w * a[3]); ok = true; }   // opset 10
+                }
+                if (ok) dims[out] = o;
+            }
+        } else if (n.op == "Shape") {
+            const Dim* d = in_dim(0);
+            if (d) { cvals[out] = {1.0, (double)d->c, (double)d->h, (double)d->w}; shape_nodes.insert(out); }
+        } else if (n.op == "Constant") {
+            auto it = n.attrs.find("value");
+            if (it != n.attrs.end() && it->second.t.numel() <= 64) {
+                std::vector<double> v;
+                if (!it->second.t.i.empty()) v.assign(it->second.t.i.begin(), it->second.t.i.end());
+                else v.assign(it->second.t.f.begin(), it->second.t.f.end());
+                cvals[out] = v; shape_nodes.insert(out);
+            }
+        } else if (n.op == "Gather") {
+            if (get_const(n.inputs.at(0), a) && get_const(n.inputs.at(1), b) && n.attr_i("axis", 0) == 0) {
+                std::vector<double> v;
+                for (double ix : b) { long q = (long)ix; if (q < 0) q += (long)a.size(); if (q < 0 || q >= (long)a.size()) fail("Gather index out of range"); v.push_back(a[(size_t)q]); }
+                cvals[out] = v; shape_nodes.insert(out);
+            }
+        } else if (n.op == "Slice") {
+            if (get_const(n.inputs.at(0), a)) {
+                std::vector<double> st, en, ax, sp;
+                bool ok = true;
+                if (n.inputs.size() >= 3) {
+                    ok = get_const(n.inputs[1], st) && get_const(n.inputs[2], en);
+                    if (n.inputs.size() > 3 && !n.inputs[3].empty()) ok = ok && get_const(n.inputs[3], ax);
+                    if (n.inputs.size() > 4 && !n.inputs[4].empty()) ok = ok && get_const(n.inputs[4], sp);
+                } else {
+                    for (auto v : n.attr_ints("starts")) st.push_back((double)v);
+                    for (auto v : n.attr_ints("ends")) en.push_back((double)v);
+                    for (auto v : n.attr_ints("axes")) ax.push_back((double)v);
+                }
+                if (ok && st.size() == 1 && en.size() == 1 && (ax.empty() || ax[0] == 0) && (sp.empty() || sp[0] == 1)) {
+                    long L = (long)a.size(), s0 = (long)st[0], e0 = (long)std::min<double>(en[0], 1e9);
+                    if (s0 < 0) s0 += L;
+                    if (e0 < 0) e0 += L;
+                    s0 = std::max(0L, std::min(L, s0)); e0 = std::max(0L, std::min(L, e0));
+                    cvals[out] = std::vector<double>(a.begin() + s0, a.begin() + std::max(s0, e0)); shape_nodes.insert(out);
+                }
+            }
+        } else if (n.op == "Concat") {
+            std::vector<double> v;
+            bool ok = !n.inputs.empty();
+            for (auto& in : n.inputs) { if (!get_const(in, a) || dims.count(in)) { ok = false; break; } v.insert(v.end(), a.begin(), a.end()); }
+            if (ok) { cvals[out] = v; shape_nodes.insert(out); }
+        } else if (n.op == "Unsqueeze" || n.op == "Squeeze" || n.op == "Cast" || n.op == "Identity" || n.op == "Floor" || n.op == "Ceil") {
+            if (!dims.count(n.inputs.at(0)) && get_const(n.inputs[0], a)) {
+                if (n.op == "Floor" || (n.op == "Cast" && n.attr_i("to", 1) != 1 && n.attr_i("to", 1) != 11)) for (auto& v : a) v = std::floor(v);
+                if (n.op == "Ceil") for (auto& v : a) v = std::ceil(v);
+                cvals[out] = a; shape_nodes.insert(out);
+            } else if (n.op == "Identity" && in_dim(0)) dims[out] = *in_dim(0);
+        } else if ((n.op == "Mul" || n.op == "Div" || n.op == "Add" || n.op == "Sub") && n.inputs.size() == 2 &&
+                   !dims.count(n.inputs[0]) && !dims.count(n.inputs[1]) && get_const(n.inputs[0], a) && get_const(n.inputs[1], b)) {
+            const size_t L = std::max(a.size(), b.size());
+            if ((a.size() == L || a.size() == 1) && (b.size() == L || b.size() == 1)) {
+                std::vector<double> v(L);
+                for (size_t k = 0; k < L; ++k) {
+                    const double x = a[a.size() == 1 ? 0 : k], y = b[b.size() == 1 ? 0 : k];
+                    v[k] = n.op == "Mul" ? x * y : n.op == "Div" ? x / y : n.op == "Add" ? x + y : x - y;
+                }
+                cvals[out] = v; shape_nodes.insert(out);
+            }
+        } else if (n.op == "Transpose" || n.op == "Reshape" || n.op == "Flatten" || n.op == "Gemm") {
+            // leaves the 4-D NCHW domain: no Dim entry
+        } else if (in_dim(0)) {
+            dims[out] = *in_dim(0);                           // element-wise: BN, Relu, PRelu, Sigmoid, Add, ...
+        }
+    }
     // ---------------------------------------------------------------- 1. node list
     std::vector<GNode> g;
     g.reserve(m.nodes.size());
@@ -87,6 +204,8 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
         x.op = n.op; x.src = &n; x.order = ord++;
         if (n.outputs.empty()) fail("node without output");
         x.out = n.outputs[0];
+        if (shape_nodes.count(x.out)) { --ord; continue; }   // folded into a constant by the pre-pass
+        if (n.op == "Identity") fail("Identity on a tensor is not supported");
         if (n.op == "Conv") {
             const auto& w = init_of(m, n.inputs.at(1));
             if (w.dims.size() != 4 || w.dims[2] != w.dims[3]) fail("Conv weight must be [Cout,Cin/g,k,k]");
@@ -145,11 +264,11 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
     auto resize_is_up2 = [&](const GNode& r) {
         const OnnxNode& n = *r.src;
         if (n.attr_s("mode", "nearest") != "nearest") fail("Resize: only nearest supported");
-        if (n.op == "Upsample" || (n.inputs.size() > 2 && !n.inputs[2].empty() && init_of(m, n.inputs[2]).f.size() == 4)) {
-            const auto& sc = init_of(m, n.op == "Upsample" ? n.inputs.at(1) : n.inputs[2]).f;
-            return sc[0] == 1.f && sc[1] == 1.f && sc[2] == 2.f && sc[3] == 2.f;
-        }
-        fail("Resize: only constant scales [1,1,2,2] supported (shape sub-graphs are not folded yet)");
+        auto di = dims.find(n.inputs[0]);
+        auto dn = dims.find(n.outputs[0]);
+        if (di == dims.end() || dn == dims.end())
+            fail("Resize: output size is not a load-time constant (unsupported shape sub-graph)");
+        return dn->second.h == 2 * di->second.h && dn->second.w == 2 * di->second.w && dn->second.c == di->second.c;
     };
 
     // ---------------------------------------------------------------- 2. Conv/Gemm -> BN folding
@@ -424,10 +543,11 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
             auto it = vals.find(n->in[0]);
             if (it == vals.end()) fail("Reshape input undefined");
             Val v = it->second;
-            const auto& shp = init_of(m, n->src->inputs.at(1)).i;
+            std::vector<double> shp;
+            if (!get_const(n->src->inputs.at(1), shp)) fail("Reshape: target shape is not a load-time constant");
             if (shp.empty()) fail("Reshape: empty target shape");
             const PTensor& t = P.tensors[v.tensor];
-            const int64_t last = shp.back();
+            const int64_t last = (int64_t)shp.back();
             if (last <= 0 || t.elems() % (size_t)last) fail("Reshape: last dimension must be a positive divisor of the tensor size");
             const bool storage_order = v.kind == Val::NHWC4D || v.kind == Val::FLAT_STORAGE ||
                                        (v.kind == Val::NCHW4D && (t.H * t.W == 1 || t.C == 1)) ||

@@ -140,7 +140,8 @@ def make_w600k_r50(path: str, seed: int = 200) -> str:
 def make_scrfd(path: str, stage_blocks: Sequence[int] = (2, 3, 2, 6),
                stage_planes: Sequence[int] = (16, 16, 40, 72, 152, 288),
                neck_ch: int = 16, head_ch: int = 64, seed: int = 100,
-               cls_bias: float = -3.0, static_hw: int | None = None, cls_gain: float = 20.0) -> str:
+               cls_bias: float = -3.0, static_hw: int | None = None, cls_gain: float = 20.0,
+               dynamic_resize: bool = False) -> str:
     """scrfd_500m_bnkps topology; BN folded as in the public export.
 
     ``cls_gain`` / ``cls_bias`` give score logits ~ N(cls_bias, 1) on random frames so that only a
@@ -181,8 +182,18 @@ def make_scrfd(path: str, stage_blocks: Sequence[int] = (2, 3, 2, 6),
     scales = b.init("neck.up_scales", np.array([1, 1, 2, 2], np.float32))
     roi = b.init("neck.up_roi", np.zeros(0, np.float32))
     for i in (2, 1):
-        up = b.node("Resize", [lat[i], roi, scales], mode="nearest",
-                    coordinate_transformation_mode="asymmetric", nearest_mode="floor")
+        if dynamic_resize:
+            # what a dynamic-axes export of F.interpolate(x, size=prev.shape[2:]) looks like:
+            # Shape -> Slice -> Concat -> Resize(sizes); the loader must fold it to a constant
+            c0, c2, c4, ax0 = (b.init(b.uid("k"), np.array([v], np.int64)) for v in (0, 2, 4, 0))
+            hw_ = b.node("Slice", [b.node("Shape", [lat[i - 1]]), c2, c4, ax0])
+            nc_ = b.node("Slice", [b.node("Shape", [lat[i]]), c0, c2, ax0])
+            sizes = b.node("Concat", [nc_, b.node("Cast", [hw_], to=7)], axis=0)
+            up = b.node("Resize", [lat[i], roi, b.init(b.uid("noscale"), np.zeros(0, np.float32)), sizes], mode="nearest",
+                        coordinate_transformation_mode="asymmetric", nearest_mode="floor")
+        else:
+            up = b.node("Resize", [lat[i], roi, scales], mode="nearest",
+                        coordinate_transformation_mode="asymmetric", nearest_mode="floor")
         lat[i - 1] = b.node("Add", [lat[i - 1], up])
     inter = [conv(lat[i], neck_ch, neck_ch, 3, 1, f"neck.fpn_convs.{i}", False, gain=1.0) for i in range(3)]
     for i in range(2):

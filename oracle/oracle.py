@@ -129,6 +129,23 @@ def run_graph(g: onnx_min.Graph, feeds: dict) -> dict:
             assert x0.shape == x1.shape
             y = np.empty_like(x0)
             L.orc_add(_f(x0), _f(x1), C.c_size_t(x0.size), _f(y))
+        elif n.op in ("Shape", "Slice", "Concat", "Cast", "Constant", "Gather", "Unsqueeze"):
+            # small integer shape arithmetic of dynamic-axes exports (evaluated literally, as ORT does)
+            if n.op == "Shape":
+                y = np.array(i[0].shape, np.int64)
+            elif n.op == "Slice":
+                st, en = int(i[1][0]), int(i[2][0])
+                y = np.asarray(i[0])[st:en]
+            elif n.op == "Concat":
+                y = np.concatenate([np.atleast_1d(v) for v in i])
+            elif n.op == "Cast":
+                y = np.asarray(i[0]).astype(np.int64 if a.get("to", 7) == 7 else np.float32)
+            elif n.op == "Constant":
+                y = a["value"]
+            elif n.op == "Gather":
+                y = np.asarray(i[0])[np.asarray(i[1], np.int64)]
+            else:
+                y = np.atleast_1d(i[0])
         elif n.op == "Resize":
             scales = i[2] if len(i) > 2 and i[2] is not None and i[2].size else None
             if scales is not None:

@@ -88,6 +88,25 @@ def test_planner_scrfd_and_dynamic_input_defaults(models_dir):
     assert "out dets [64x15]" in pre
 
 
+def test_planner_folds_dynamic_shape_subgraphs(models_dir):
+    """Dynamic-axes exports size their Resize with Shape -> Slice -> Concat sub-graphs (what the public det_500m.onnx
+    is expected to contain): with the input size fixed at load time the planner folds them to constants."""
+    from oracle import onnx_min, oracle
+    from tests import torch_ref
+    dyn = models.make_scrfd(os.path.join(models_dir, "s_dynresize.onnx"), (1, 2, 1, 2), (8, 8, 16, 24, 32, 48), 8, 16, seed=2,
+                            cls_bias=-2.0, dynamic_resize=True)
+    ref = util.tiny_scrfd(models_dir, hw=None)
+    g = onnx_min.load(dyn)
+    assert {"Shape", "Slice", "Concat", "Cast"} <= {n.op for n in g.nodes}
+    a, b = fa.plan_describe(dyn, 96, 160), fa.plan_describe(ref, 96, 160)
+    strip = lambda d: [l for l in d.splitlines() if re.match(r"^\d+ |^out ", l)]
+    assert strip(a) == strip(b) and a.count("+res(up2x)") == 2            # identical plan, sub-graphs gone
+    x = np.random.default_rng(0).uniform(-1, 1, (1, 3, 64, 96)).astype(np.float32)
+    oa, ob = oracle.run_graph(g, {"input.1": x}), torch_ref.run_graph(g, {"input.1": x})
+    for k in oa:
+        np.testing.assert_allclose(oa[k], ob[k], rtol=2e-5, atol=2e-5)
+
+
 def test_onnx_writer_reader_round_trip(models_dir):
     from oracle import onnx_min
     p = util.tiny_scrfd(models_dir, hw=None)

@@ -35,6 +35,14 @@ def run_graph(path_or_graph, feeds: dict, dtype=torch.float64) -> dict:
             y = torch.sigmoid(i[0])
         elif n.op == "Add":
             y = i[0] + i[1]
+        elif n.op == "Shape":
+            y = torch.tensor(list(i[0].shape), dtype=torch.int64)
+        elif n.op == "Slice":
+            y = i[0][int(i[1][0]):int(i[2][0])]
+        elif n.op == "Concat":
+            y = torch.cat([v.reshape(-1) for v in i])
+        elif n.op == "Cast":
+            y = i[0].to(torch.int64)
         elif n.op == "Resize":
             s = int(i[2][2]) if len(i) > 2 and i[2] is not None and i[2].numel() else int(i[3][2]) // i[0].shape[2]
             y = F.interpolate(i[0], scale_factor=s, mode="nearest")
