@@ -405,3 +405,23 @@ def test_streamk_is_deterministic_and_matches_plain_tiles():
     a, b = res[1].astype(np.float64), res[0].astype(np.float64)
     cos = (a * b).sum(1) / np.linalg.norm(a, axis=1) / np.linalg.norm(b, axis=1)
     assert (1.0 - cos).max() < 1e-6, (1.0 - cos).max()             # different K cut points: fp32 rounding only
+
+
+def test_cli_modes(models_dir, tmp_path, capsys):
+    """Text-mode counterpart of main.cpp's detect / compare / simple modes."""
+    from facerecognizeonnx_amd import cli
+    dpath = util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0)
+    rpath = util.tiny_iresnet(models_dir)
+    imgs = util.frames_u8(2, 120, 160, seed=77, smooth=True)
+    pa, pb = str(tmp_path / "a.npy"), str(tmp_path / "b.npy")
+    np.save(pa, imgs[0]); np.save(pb, imgs[1])
+    assert cli.main(["detect", pa, "--det", dpath]) == 0
+    out = capsys.readouterr().out
+    det = fa.FaceDetector(); assert det.loadModel(dpath)
+    assert f"Detected {len(det.detect(imgs[0]))} faces" in out and "Face 0: box=" in out
+    assert cli.main(["compare", pa, pb, "--det", dpath, "--rec", rpath]) == 0
+    out = capsys.readouterr().out
+    assert "Feature dimension: 512" in out and "Similarity: " in out
+    assert cli.main(["simple", pa, pa, "--rec", rpath]) == 0
+    assert "Same person" in capsys.readouterr().out                       # identical images -> similarity 1
+    assert cli.main(["detect", pa, "--det", str(tmp_path / "missing.onnx")]) == -1
