@@ -70,6 +70,7 @@ PROTOTYPES = {
     "fh_rec_align_dev": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _i, _vp, _vp, _vp]),
     "fh_rec_embed_faces_dev": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _i, _vp, _vp, _vp]),
     "fh_pipeline_run_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "fh_pipeline_submit_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fh_gallery_create": (_vp, [_i]),
     "fh_gallery_destroy": (None, [_vp]),
     "fh_gallery_upload": (_i, [_vp, _vp, _ll, _i, _ll]),

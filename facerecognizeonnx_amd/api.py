@@ -192,6 +192,16 @@ def pipeline_run_dev(det: FaceDetector, rec: FaceRecognizer, frames_ptr: int, n:
                                                 frame_of_ptr, emb_ptr, stream), "fh_pipeline_run_dev")
 
 
+def pipeline_submit_dev(det: FaceDetector, rec: FaceRecognizer, frames_ptr: int, n: int, rows: int, cols: int,
+                        faces_per_frame: int, faces_ptr: int, frame_of_ptr: int, emb_ptr: int, total_ptr: int,
+                        stream_det: int, stream_rec: int, scoreThreshold: float = 0.5, nmsThreshold: float = 0.4) -> int:
+    """Asynchronous detect -> align -> embed: detector on stream_det, recogniser on stream_rec, no host sync."""
+    step = cols * 3
+    return check(_lib.lib().fh_pipeline_submit_dev(det.handle, rec.handle, frames_ptr, n, rows, cols, step, rows * step,
+                                                   scoreThreshold, nmsThreshold, faces_per_frame, faces_ptr, frame_of_ptr,
+                                                   emb_ptr, total_ptr, stream_det, stream_rec), "fh_pipeline_submit_dev")
+
+
 class Gallery:
     """1:N generalisation of compareFaces: top-k mapped scores (dot+1)/2 over enrolled rows."""
 

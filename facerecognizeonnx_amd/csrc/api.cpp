@@ -34,6 +34,8 @@ struct fh_det {
     fh::Detector det;
     fh::DevBuf img, out, cnt;            // staging for the host-pointer API
     fh::DevBuf p_det, p_cnt, p_total;    // pipeline scratch
+    hipEvent_t ev_sel = nullptr;         // detect -> embed hand-off between two streams
+    ~fh_det() { if (ev_sel) (void)hipEventDestroy(ev_sel); }
 };
 struct fh_rec {
     explicit fh_rec(const char* p) : rec(p) {}
@@ -259,6 +261,33 @@ int fh_pipeline_run_dev(fh_det* d, fh_rec* r, const uint8_t* frames, int n, int 
         FH_HIP(hipMemcpyAsync(&total, d->p_total.p, sizeof(int), hipMemcpyDeviceToHost, s));
         FH_HIP(hipStreamSynchronize(s));
         return total;
+    });
+}
+
+// Fully asynchronous form for streaming callers: detect (+ decode + NMS + face selection) is queued on
+// stream_det, align + embed on stream_rec behind an event, nothing synchronises with the host and the
+// face count stays on the device (d_total).  Submitting batch k+1 right after batch k lets the
+// HBM-bound detector of k+1 run beside the MFMA-bound recogniser of k on the same GPU.
+int fh_pipeline_submit_dev(fh_det* d, fh_rec* r, const uint8_t* frames, int n, int rows, int cols, int step, long long stride,
+                           float score_thr, float nms_thr, int F, fh_face* faces, int* frame_of, float* emb, int* d_total,
+                           void* stream_det, void* stream_rec) {
+    if (!d || !r || !frames || !faces || !frame_of || !emb || !d_total) return arg_error("fh_pipeline_submit_dev: null argument");
+    if (n <= 0 || n > 4096 || rows <= 0 || cols <= 0 || F <= 0) return arg_error("fh_pipeline_submit_dev: bad size");
+    return guarded([&] {
+        hipStream_t sd = S(stream_det), sr = S(stream_rec);
+        d->p_det.ensure((size_t)n * F * sizeof(fh_face));
+        d->p_cnt.ensure((size_t)n * sizeof(int));
+        if (!d->ev_sel) FH_HIP(hipEventCreateWithFlags(&d->ev_sel, hipEventDisableTiming));
+        d->det.detect_dev(frames, n, rows, cols, step, (long)stride, score_thr, nms_thr, d->p_det.as<fh::FaceRec>(), F, d->p_cnt.as<int>(), sd);
+        fh::launch_select_faces(d->p_det.as<fh::FaceRec>(), d->p_cnt.as<int>(), n, F, F, reinterpret_cast<fh::FaceRec*>(faces), frame_of,
+                                d_total, sd);
+        if (sd != sr) {
+            FH_HIP(hipEventRecord(d->ev_sel, sd));
+            FH_HIP(hipStreamWaitEvent(sr, d->ev_sel, 0));
+        }
+        r->rec.embed_faces_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, n * F, emb,
+                               nullptr, sr, d_total);
+        return n * F;
     });
 }
 

@@ -116,6 +116,18 @@ FH_API int fh_pipeline_run_dev(fh_det* d, fh_rec* r, const uint8_t* d_frames, in
                                long long frame_stride, float score_thr, float nms_thr, int faces_per_frame,
                                fh_face* d_faces, int* d_frame_of, float* d_emb, void* stream);
 
+/* Asynchronous form for streaming callers (the testWebcam loop shape, src/main.cpp:214-258, over batches):
+ * detect + decode + NMS + face selection are queued on stream_det, align + embed on stream_rec behind an
+ * event; nothing synchronises with the host.  d_total (device int) receives the number of faces; all
+ * n*faces_per_frame embedding slots are computed, slots >= *d_total are empty.  Every buffer passed in
+ * (frames included) must stay untouched until stream_rec has drained; give each in-flight batch its own
+ * d_faces / d_frame_of / d_emb / d_total.  Submitting batch k+1 straight after batch k overlaps the
+ * HBM-bound detector with the MFMA-bound recogniser.  Returns the number of slots or < 0. */
+FH_API int fh_pipeline_submit_dev(fh_det* d, fh_rec* r, const uint8_t* d_frames, int n, int rows, int cols, int step,
+                                  long long frame_stride, float score_thr, float nms_thr, int faces_per_frame,
+                                  fh_face* d_faces, int* d_frame_of, float* d_emb, int* d_total, void* stream_det,
+                                  void* stream_rec);
+
 /* ---- gallery (1:N compareFaces): rows are L2-normalised features; scores are (dot+1)/2. */
 FH_API fh_gallery* fh_gallery_create(int dim);
 FH_API void fh_gallery_destroy(fh_gallery* g);
