@@ -425,3 +425,33 @@ def test_cli_modes(models_dir, tmp_path, capsys):
     assert cli.main(["simple", pa, pa, "--rec", rpath]) == 0
     assert "Same person" in capsys.readouterr().out                       # identical images -> similarity 1
     assert cli.main(["detect", pa, "--det", str(tmp_path / "missing.onnx")]) == -1
+
+
+def test_async_two_stream_pipeline_equals_serial(models_dir):
+    """fh_pipeline_submit_dev (detector and recogniser on different HIP streams, several batches in flight, no host
+    sync) must give exactly the serial entry point's faces and embeddings."""
+    det = fa.FaceDetector(); rec = fa.FaceRecognizer()
+    assert det.loadModel(util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0)) and rec.loadModel(util.tiny_iresnet(models_dir))
+    n, F, K = 5, 3, 4
+    batches = [dev(util.frames_u8(n, 128, 128, seed=40 + k, smooth=True)) for k in range(K)]
+    ref = []
+    for k in range(K):
+        f = torch.zeros((n * F, 15), device="cuda"); o = torch.zeros(n * F, dtype=torch.int32, device="cuda"); e = torch.zeros((n * F, 512), device="cuda")
+        t = fa.pipeline_run_dev(det, rec, batches[k].data_ptr(), n, 128, 128, F, f.data_ptr(), o.data_ptr(), e.data_ptr())
+        torch.cuda.synchronize()
+        ref.append((t, f[:t].clone(), o[:t].clone(), e[:t].clone()))
+    sd, sr = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for k in range(K):
+        f = torch.zeros((n * F, 15), device="cuda"); o = torch.zeros(n * F, dtype=torch.int32, device="cuda")
+        e = torch.zeros((n * F, 512), device="cuda"); t = torch.zeros(1, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        assert fa.pipeline_submit_dev(det, rec, batches[k].data_ptr(), n, 128, 128, F, f.data_ptr(), o.data_ptr(), e.data_ptr(),
+                                      t.data_ptr(), sd.cuda_stream, sr.cuda_stream) == n * F
+        outs.append((t, f, o, e))
+    torch.cuda.synchronize()
+    for (t, f, o, e), (rt, rf, ro, re_) in zip(outs, ref):
+        tt = int(t.item())
+        assert tt == rt and rt > 0
+        assert torch.equal(f[:tt].view(torch.int32), rf.view(torch.int32))        # 60-byte records, compared bitwise
+        assert torch.equal(o[:tt], ro) and torch.equal(e[:tt], re_)
