@@ -436,7 +436,7 @@ static int num_cus() {
     }
     return g_num_cus;
 }
-static const float* zero_line() {                      // 8 KiB of zeros: a padded tap streams up to Cin*4 bytes from it
+const float* conv_zero_line() {                      // 8 KiB of zeros: a padded tap streams up to Cin*4 bytes from it
     if (!g_zeros) {
         void* p = nullptr;
         if (hipMalloc(&p, 8192) == hipSuccess) { (void)hipMemset(p, 0, 8192); g_zeros = (const float*)p; }
@@ -453,7 +453,7 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
     const int T = tiles_m * tiles_n;
     const int chunks = a.Kpad / 32;
     const int S = num_cus() * resident_per_cu;
-    a.zeros = zero_line();
+    a.zeros = conv_zero_line();
     int full = (T / S) * S;
     int R = T - full;
     int sk_wgs = 0;

@@ -1,0 +1,210 @@
+// dwpw_mfma.hip — depthwise 3x3 stride-1 (+bias +ReLU) fused with the pointwise 1x1 convolution that
+// consumes it: the MobileNet "conv_dw" block of SCRFD (ONNX Conv(group=C) -> Relu -> Conv 1x1 -> Relu,
+// executed by ORT inside session_->Run, reference src/face_detector.cpp:179-183).
+//
+// Run separately, these HBM-bound blocks write the depthwise result and read it straight back —
+// as much traffic as the block's real input and output together.  Here one workgroup owns a SPATIAL
+// tile of 8 x 16 output pixels and walks the channels in chunks of 32:
+//   1. the (8+2) x (16+2) input halo of the chunk goes global -> LDS by LDS-DMA (each element once,
+//      coalesced 128-byte pixel rows; out-of-image pixels and channels >= C come from the zero line),
+//      together with the pointwise weight chunk [BN][32];
+//   2. the depthwise 3x3 (+bias +activation) is evaluated from LDS on the vector ALU, 4 channels per
+//      lane, and written to LDS as the GEMM's A tile [128 pixels][32 k] (XOR-swizzled like conv_mfma.hip);
+//   3. the pointwise product accumulates on v_mfma_f32_32x32x2_f32 exactly as in conv_igemm_kernel.
+// The intermediate tensor never exists in HBM.  Two barriers per chunk, no double buffering: the
+// layers are bandwidth-bound and >= 2 workgroups per CU overlap each other's phases.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "plan.h"
+
+namespace fh {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void dwpw_dma16(const float* src, v4f* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#else
+    (void)src; (void)dst;
+#endif
+}
+
+constexpr int DP_TH = 8, DP_TW = 16, DP_BM = DP_TH * DP_TW;            // 128 output pixels per tile
+constexpr int DP_HW = DP_TW + 2, DP_HALO = (DP_TH + 2) * DP_HW;         // 10 x 18 = 180 halo pixels
+
+template <int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_n) {
+    constexpr int BM = DP_BM;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int HALO_SLOTS = (DP_HALO * 8 + 255) / 256 * 256;           // float4 slots, whole DMA passes
+    __shared__ v4f lds[HALO_SLOTS + BM * 8 + BN * 8];
+    v4f* const halo = lds;
+    v4f* const At = lds + HALO_SLOTS;
+    v4f* const Wt = At + BM * 8;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int C = p.Cin;
+    int t = blockIdx.x;
+    const int tile_n = t % tiles_n; t /= tiles_n;
+    const int tx0 = (t % tiles_x) * DP_TW; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * DP_TH;
+    const int n = t / tiles_y;
+    const int n0 = tile_n * BN;
+    const int chunks = p.Kpad / 32;
+    const float* img = p.in + (size_t)n * p.H * p.W * C;                  // stride 1: H x W is also the output grid
+
+    // ---- halo loader: slot s = 256*j + tid covers halo pixel s>>3, 16-byte column s&7
+    constexpr int HP = HALO_SLOTS / 256;
+    long h_off[HP];                                                        // float offset of (pixel, column 0) or -1
+#pragma unroll
+    for (int j = 0; j < HP; ++j) {
+        const int s = j * 256 + tid, hp = s >> 3;
+        h_off[j] = -1;
+        if (hp < DP_HALO) {
+            const int hy = hp / DP_HW, hx = hp - hy * DP_HW;
+            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) h_off[j] = ((long)iy * p.W + ix) * C + (s & 7) * 4;
+        }
+    }
+    const int hq = tid & 7;                                                // same for every pass (256 % 8 == 0)
+    // ---- pointwise weight loader (as conv_mfma.hip: LDS-DMA, swizzle on the source column)
+    const int lrow = tid >> 3;
+    const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);
+    constexpr int BL = BN / 32;
+    const char* w_base = reinterpret_cast<const char*>(p.wt) + (size_t)n0 * p.Kpad * 4;
+    unsigned w_off[BL];
+#pragma unroll
+    for (int i = 0; i < BL; ++i) w_off[i] = (unsigned)(((lrow + i * 32) * p.Kpad + lqs * 4) * 4);
+
+    // ---- depthwise producer: thread -> 16-byte column dq of pixels dp + 32*i
+    const int dq = tid & 7, dp = tid >> 3;
+    const int fr = lane & 31, fh2 = lane >> 5, fsw = (fr >> 1) & 7;
+
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    for (int kc = 0; kc < chunks; ++kc) {
+        const int c0 = kc * 32;
+        const bool hvalid = c0 + hq * 4 < C;
+        __syncthreads();                                                   // previous chunk: halo + fragments fully consumed
+#pragma unroll
+        for (int j = 0; j < HP; ++j) {
+            const float* src = (h_off[j] >= 0 && hvalid) ? img + h_off[j] + c0 : p.zeros;
+            dwpw_dma16(src, halo + j * 256 + wid * 64);
+        }
+#pragma unroll
+        for (int i = 0; i < BL; ++i) dwpw_dma16(reinterpret_cast<const float*>(w_base + w_off[i]), Wt + i * 256 + wid * 64);
+        w_base += 128;
+        // depthwise weights / bias of this thread's 4 channels (channels >= C: zero line -> zero output)
+        const int cw = c0 + dq * 4;
+        const bool cvalid = cw < C;
+        v4f wk[9], b4;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const v4f*>(cvalid ? p.dw_w + (size_t)k * C + cw : p.zeros);
+        b4 = *reinterpret_cast<const v4f*>(cvalid ? p.dw_b + cw : p.zeros);
+        __syncthreads();                                                   // halo + weights landed (barrier drains vmcnt)
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) {
+            const int px = dp + 32 * i;
+            const int py = px / DP_TW, pxx = px - py * DP_TW;
+            v4f a = b4;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) a += halo[((py + ky) * DP_HW + pxx + kx) * 8 + dq] * wk[ky * 3 + kx];
+            if (p.dw_act == (int)Act::RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : 0.f;
+            }
+            At[px * 8 + (dq ^ ((px >> 1) & 7))] = a;
+        }
+        __syncthreads();                                                   // A tile complete
+        const v4f* X = At + (wm * TM * 32 + fr) * 8;
+        const v4f* Wp = Wt + (wn * TN * 32 + fr) * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = (2 * s + fh2) ^ fsw;
+            v4f x[TM], w[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) x[i] = X[i * 32 * 8 + col];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) w[j] = Wp[j * 32 * 8 + col];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j][e], x[i][e], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane = pixel (lane&31 within each 32-row block), accumulator quads = 4 consecutive channels
+    const bool vec = (p.Cout & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = (wm * TM + i) * 32 + fr;
+        const int oy = ty0 + r / DP_TW, ox = tx0 + r % DP_TW;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        float* __restrict__ orow = p.out1 + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.Cout;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int cb = n0 + (wn * TN + j) * 32 + 4 * fh2;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cb + 8 * g;
+                if (co >= p.Cout) continue;
+                if (vec) {
+                    const v4f bb = *reinterpret_cast<const v4f*>(p.bias + co);
+                    v4f v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float u = acc[i][j][4 * g + c] + bb[c];
+                        if (p.act == (int)Act::RELU) u = u > 0.f ? u : 0.f;
+                        v[c] = u;
+                    }
+                    *reinterpret_cast<v4f*>(orow + co) = v;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        if (co + c >= p.Cout) continue;
+                        float u = acc[i][j][4 * g + c] + p.bias[co + c];
+                        if (p.act == (int)Act::RELU) u = u > 0.f ? u : 0.f;
+                        orow[co + c] = u;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int BN, int WM, int WN>
+static void launch_dwpw_cfg(const ConvArgs& a, hipStream_t s) {
+    const int tiles_x = (a.Wo + DP_TW - 1) / DP_TW, tiles_y = (a.Ho + DP_TH - 1) / DP_TH, tiles_n = (a.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN>), dim3((unsigned)(a.B * tiles_y * tiles_x * tiles_n)), dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
+}
+
+// a.in = depthwise input [B,H,W,C] (stride 1: H x W = output grid), a.Cin = C, a.wt = packed pointwise weights
+// [..][conv_kpad(C)], a.dw_w [9][C], a.dw_b [C]; activation of the pointwise part limited to NONE / RELU.
+void launch_dwpw(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    a.zeros = conv_zero_line();
+    if ((long)a.B * a.Ho * a.Wo <= 0) return;
+    KernelTimer& timer = KernelTimer::get();
+    timer.begin(s);
+    if (a.Cout <= 32) launch_dwpw_cfg<32, 4, 1>(a, s);
+    else if (a.Cout <= 64) launch_dwpw_cfg<64, 2, 2>(a, s);
+    else launch_dwpw_cfg<128, 2, 2>(a, s);
+    timer.end(s, 4, a.t_flops, a.t_bytes);
+}
+
+}  // namespace fh

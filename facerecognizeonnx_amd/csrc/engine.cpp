@@ -88,7 +88,11 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
     for (size_t i = 0; i < plan_.ops.size(); ++i) {
         const POp& op = plan_.ops[i];
         DevOp& d = dev_[i];
-        if (op.kind == OpKind::CONV || op.kind == OpKind::GEMM) {
+        if (op.kind == OpKind::DWPW) {
+            d.dww = push(op.dw_weight.data(), op.dw_weight.size());
+            d.dwb = push(op.dw_bias.data(), op.dw_bias.size());
+        }
+        if (op.kind == OpKind::CONV || op.kind == OpKind::GEMM || op.kind == OpKind::DWPW) {
             const int Ktot = op.ks * op.ks * op.Cin;
             d.Kpad = conv_kpad(Ktot);
             const int rows = conv_wt_rows(op.Cout);
@@ -158,7 +162,7 @@ void Net::run(int batch, hipStream_t s, int first_op) {
         const POp& op = plan_.ops[i];
         const DevOp& d = dev_[i];
         int tag = 5;
-        const bool dense = op.kind == OpKind::CONV || op.kind == OpKind::GEMM;   // the conv launcher times its own kernels
+        const bool dense = op.kind == OpKind::CONV || op.kind == OpKind::GEMM || op.kind == OpKind::DWPW;   // the conv launcher times its own kernels
         if (!dense) timer.begin(s);
         switch (op.kind) {
             case OpKind::CONV:
@@ -187,6 +191,18 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 a.t_flops = 2.0 * op.macs * batch; a.t_bytes = op.bytes * batch;
                 launch_conv(a, cfg, s);
                 tag = cfg;
+                break;
+            }
+            case OpKind::DWPW: {
+                ConvArgs a{};
+                a.in = tensor_ptr(op.in);
+                a.wt = P + d.wt; a.bias = P + d.bias;
+                a.out1 = tensor_ptr(op.out);
+                a.dw_w = P + d.dww; a.dw_b = P + d.dwb; a.dw_act = (int)op.dw_act;
+                a.B = batch; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
+                a.ks = 1; a.stride = 1; a.pad = 0; a.Kpad = d.Kpad; a.act = (int)op.act;
+                a.t_flops = 2.0 * op.macs * batch; a.t_bytes = op.bytes * batch;
+                launch_dwpw(a, s);
                 break;
             }
             case OpKind::DWCONV:

@@ -50,6 +50,7 @@ class Net {
         size_t wt = 0, bias = 0, slope = 0, s2 = 0, t2 = 0;   // float offsets into params_
         bool has_slope = false, has_aff = false;
         size_t w27 = 0;                                       // stem layout [27][Cout] (op 0 only)
+        size_t dww = 0, dwb = 0;                              // fused depthwise front end (DWPW)
         int Kpad = 0;
     };
     float* tensor_ptr(int t) const { return arena_.as<float>() + plan_.tensors[t].offset * (size_t)cap_; }

@@ -54,6 +54,9 @@ struct ConvArgs {
     int Kpad;               // multiple of 32
     int act;                // fh::Act
     int res_mode;           // fh::ResMode
+    const float* dw_w;      // fused depthwise 3x3 front end (launch_dwpw): weights [9][Cin], bias [Cin], activation
+    const float* dw_b;
+    int dw_act;
     int n_outs;             // > 0: merged sibling convs — channels [oc0[g], oc0[g+1]) go to outs[g] with act oact[g]
     float* outs[3];
     int oc0[4];
@@ -66,6 +69,9 @@ struct ConvArgs {
 // cfg: 0 = 128x128 tile, 1 = 256x64, 2 = 128x32, 3 = 64x64 (256 threads each); -1 = choose.
 void launch_conv(const ConvArgs& a, int cfg, hipStream_t s);
 int conv_pick_cfg(long M, int Cout);
+const float* conv_zero_line();                // 8 KiB of device zeros (target of padded / dead loads)
+// depthwise 3x3 stride 1 (+bias +act) fused with the 1x1 conv that consumes it (dwpw_mfma.hip)
+void launch_dwpw(const ConvArgs& a, hipStream_t s);
 int conv_wt_rows(int Cout);                   // packed weight rows (Cout rounded up to 128)
 size_t conv_slab_floats();
 // host: plan-layout weights [Cout][ks*ks][Cin] -> packed [conv_wt_rows(Cout)][conv_kpad(ks*ks*Cin)] (dst pre-zeroed)

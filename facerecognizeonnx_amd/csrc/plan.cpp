@@ -604,6 +604,42 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
         P.ops.swap(kept);
     }
 
+    // ---------------------------------------------------------------- 7c. depthwise 3x3 (stride 1) -> pointwise 1x1 fusion
+    // (large maps only: the fused kernel works on 8x16 spatial tiles, small maps would be mostly padding)
+    {
+        auto uses = [&](int t) {
+            int c = 0;
+            for (auto& o : P.ops) for (int x : {o.in, o.in2, o.res}) if (x == t) ++c;
+            for (auto& o : m.outputs) { auto it = vals.find(o.name); if (it != vals.end() && it->second.tensor == t) ++c; }
+            return c;
+        };
+        std::vector<bool> gone(P.ops.size(), false);
+        for (size_t i = 0; i < P.ops.size(); ++i) {
+            POp& d = P.ops[i];
+            if (d.kind != OpKind::DWCONV || d.stride != 1 || d.Ho * d.Wo < 1600 || uses(d.out) != 1) continue;
+            for (size_t j = i + 1; j < P.ops.size(); ++j) {
+                POp& c = P.ops[j];
+                if (c.in != d.out) continue;
+                const bool ok = c.kind == OpKind::CONV && c.ks == 1 && c.stride == 1 && c.res < 0 && c.out2 < 0 && c.outs.empty() &&
+                                c.Cin % 4 == 0 && c.Cout <= 128 &&      // one n-tile: the depthwise part is never recomputed
+                                (c.act == Act::NONE || c.act == Act::RELU) && (d.act == Act::NONE || d.act == Act::RELU);
+                if (!ok) break;
+                POp f = c;
+                f.kind = OpKind::DWPW;
+                f.name = d.name + "+" + c.name;
+                f.in = d.in;
+                f.dw_weight = d.weight; f.dw_bias = d.bias; f.dw_act = d.act;
+                f.macs = d.macs + c.macs;
+                P.ops[j] = std::move(f);
+                gone[i] = true;
+                break;
+            }
+        }
+        std::vector<POp> kept;
+        for (size_t i = 0; i < P.ops.size(); ++i) if (!gone[i]) kept.push_back(std::move(P.ops[i]));
+        P.ops.swap(kept);
+    }
+
     // ---------------------------------------------------------------- 8. outputs
     for (const auto& o : m.outputs) {
         auto it = vals.find(o.name);
@@ -635,7 +671,7 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
     for (auto& t : P.tensors) {
         if (t.is_input) t.first = 0;
         if (t.is_input || t.is_output) t.last = nops;       // keep for the caller
-        if (t.first < 0) { t.first = 0; t.last = 0; }
+        if (t.first < 0) { t.first = -1; t.last = -1; }         // fused away: never materialised
     }
     {
         // greedy first-fit on (lifetime, size); offsets aligned to 64 floats (256 B)
@@ -645,6 +681,7 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
         std::vector<int> placed;
         for (int id : order) {
             PTensor& t = P.tensors[id];
+            if (t.first < 0) continue;
             const size_t sz = (t.elems() + 63) / 64 * 64;
             std::vector<std::pair<size_t, size_t>> busy;
             for (int q : placed) {
@@ -668,13 +705,13 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
         op.bytes = b;
         P.macs += op.macs;
         P.act_bytes += b;
-        P.weight_bytes += (double)(op.weight.size() + op.bias.size() + op.slope.size() + op.s2.size() + op.t2.size()) * 4;
+        P.weight_bytes += (double)(op.weight.size() + op.bias.size() + op.slope.size() + op.s2.size() + op.t2.size() + op.dw_weight.size() + op.dw_bias.size()) * 4;
     }
     return P;
 }
 
 std::string Plan::describe() const {
-    static const char* kinds[] = {"CONV", "DWCONV", "GEMM", "AFFINE", "ACT", "ADD", "UPSAMPLE"};
+    static const char* kinds[] = {"CONV", "DWCONV", "GEMM", "AFFINE", "ACT", "ADD", "UPSAMPLE", "DW+PW"};
     static const char* acts[] = {"", "+relu", "+prelu", "+sigmoid"};
     std::ostringstream os;
     os << "input " << inH << "x" << inW << "  ops " << ops.size() << "  tensors " << tensors.size()

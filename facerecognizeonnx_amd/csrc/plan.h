@@ -14,7 +14,7 @@ namespace fh {
 
 enum class Act : int { NONE = 0, RELU = 1, PRELU = 2, SIGMOID = 3 };
 enum class ResMode : int { NONE = 0, SAME = 1, UP2X = 2 };
-enum class OpKind : int { CONV = 0, DWCONV = 1, GEMM = 2, AFFINE = 3, ACT = 4, ADD = 5, UPSAMPLE = 6 };
+enum class OpKind : int { CONV = 0, DWCONV = 1, GEMM = 2, AFFINE = 3, ACT = 4, ADD = 5, UPSAMPLE = 6, DWPW = 7 };
 
 struct PTensor {
     std::string name;
@@ -44,6 +44,9 @@ struct POp {
     // SCRFD cls/reg/kps branches): one GEMM with Cout = sum, channel range [out_c0[g], out_c0[g+1]) goes
     // to tensor outs[g] with activation out_act[g].  Empty = ordinary single-output conv.
     std::vector<int> outs, out_c0, out_act;
+    // DWPW: a stride-1 depthwise 3x3 (dw_weight [9][Cin], dw_bias, dw_act) feeding this op's 1x1 convolution
+    std::vector<float> dw_weight, dw_bias;
+    Act dw_act = Act::NONE;
     double macs = 0;                  // multiply-accumulates per image
     double bytes = 0;                 // algorithmic activation bytes per image (in + res + outs)
 };
