@@ -182,10 +182,17 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
     int tile, c_begin, c_end, nseg = 1, seg1_len = 0;
     bool to_slab = false;
     int sk_w = 0;
+    // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  Give every XCD
+    // a CONTIGUOUS range of tiles instead, so that the tiles_n workgroups that read the same pixels (and the
+    // neighbours that share their halo rows) hit the same L2 instead of fetching the input once per XCD.
+    auto xcd_contiguous = [](int b, int n) {
+        const int q = n >> 3, r = n & 7, x = b & 7;
+        return x * q + min(x, r) + (b >> 3);
+    };
     if ((int)blockIdx.x < p.sk_full) {
-        tile = blockIdx.x; c_begin = 0; c_end = chunks;
+        tile = xcd_contiguous(blockIdx.x, p.sk_full); c_begin = 0; c_end = chunks;
     } else {
-        sk_w = blockIdx.x - p.sk_full;
+        sk_w = xcd_contiguous(blockIdx.x - p.sk_full, gridDim.x - p.sk_full);
         const int u0 = sk_w * p.sk_q;
         const int u1 = min(p.sk_units, u0 + p.sk_q);
         tile = p.sk_full + u0 / chunks;
