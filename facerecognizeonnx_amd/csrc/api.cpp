@@ -361,7 +361,7 @@ int fh_conv_forward_dev(const float* in, const float* wt, const float* bias, flo
         a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1;
         a.Kpad = kpad;
         static fh::DevBuf slabs;                 // test entry point only: one shared workspace
-        slabs.ensure(fh::conv_slab_floats() * sizeof(float));
+        if (!slabs.p) { slabs.ensure(fh::conv_slab_floats() * sizeof(float)); fh::conv_workspace_init(slabs.as<float>()); }
         a.slabs = slabs.as<float>(); a.sk_enable = 1;
         fh::launch_conv(a, cfg, S(stream));
         FH_HIP(hipGetLastError());

@@ -26,13 +26,18 @@
 //     -> store, plus an optional second output  y*s2 + t2  (the next block's pre-conv BN).
 //
 // Work distribution ("stream-K remainder"): with T tiles and S workgroups resident on the chip,
-// the first floor(T/S)*S tiles are computed one per workgroup; the K-chunks of the remaining
-// R < S tiles are dealt out evenly over up to S further workgroups of the same launch, each
-// covering a contiguous run of chunks (at most two tile segments).  Segments store their raw
-// accumulators to slabs; a small fix-up kernel sums a tile's slabs in K order and runs the same
-// epilogue.  Deterministic (no atomics), no inter-workgroup hand-off inside a launch, and it
-// doubles as split-K for the 25088-deep FC and for small-batch late stages.
+// the first floor(T/S)*S tiles are computed one per workgroup.  The remaining R < S tiles would
+// leave S-R slots idle, so their K range is cut: R OWNER workgroups compute the first q_o chunks
+// of their tile, H <= S-R HELPER workgroups (lower block indices, so they are dispatched first)
+// share the other chunks evenly, each covering a contiguous run that may span several tiles.
+// A helper stores its raw accumulators to a slab and publishes it (agent-scope release + one
+// counter add per tile); the owner polls its tile's counter, acquires, adds the <= 3 slabs in K
+// order and runs the epilogue — deterministic, no float atomics, no second kernel.  When a tile
+// would need more than 3 slabs (the 25088-deep FC as split-K, tiny remainders) there are no
+// owners: every segment goes to a slab and conv_fixup_kernel sums them in a second launch.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "kernels.h"
 #include "plan.h"
@@ -41,6 +46,10 @@ namespace fh {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+
+// stream-K workspace: accumulator slabs followed by one counter word per remainder tile
+constexpr size_t SK_SLAB_FLOATS = (size_t)2 * 1280 * 128 * 128;
+constexpr size_t SK_COUNTERS = 4096;
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == (int)Act::RELU) return v > 0.f ? v : 0.f;
@@ -178,10 +187,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
     const int fr = lane & 31, fh2 = lane >> 5;
     const int fsw = (fr >> 1) & 7;
 
-    // ---- which tile(s) and which K range: full tiles first, then stream-K segments
-    int tile, c_begin, c_end, nseg = 1, seg1_len = 0;
-    bool to_slab = false;
-    int sk_w = 0;
+    // ---- which tile(s) and which K range: plain tiles first, then helpers, then owners
     // Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8), each with its own L2.  Give every XCD
     // a CONTIGUOUS range of tiles instead, so that the tiles_n workgroups that read the same pixels (and the
     // neighbours that share their halo rows) hit the same L2 instead of fetching the input once per XCD.
@@ -189,22 +195,34 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
         const int q = n >> 3, r = n & 7, x = b & 7;
         return x * q + min(x, r) + (b >> 3);
     };
+    enum { PLAIN = 0, HELPER = 1, OWNER = 2 };
+    int role = PLAIN, tile = 0, c_begin = 0, c_end = chunks;
+    int hu = 0, hu_end = 0, helper_id = 0;                  // helper: its run of units [hu, hu_end)
+    const int Kh = chunks - p.sk_owner_chunks;              // chunks per remainder tile that helpers compute
     if ((int)blockIdx.x < p.sk_full) {
-        tile = xcd_contiguous(blockIdx.x, p.sk_full); c_begin = 0; c_end = chunks;
+        tile = xcd_contiguous(blockIdx.x, p.sk_full);
+    } else if ((int)blockIdx.x < p.sk_full + p.sk_helpers) {
+        role = HELPER;
+        helper_id = xcd_contiguous(blockIdx.x - p.sk_full, p.sk_helpers);
+        hu = helper_id * p.sk_q;
+        hu_end = min(p.sk_units, hu + p.sk_q);
     } else {
-        sk_w = xcd_contiguous(blockIdx.x - p.sk_full, gridDim.x - p.sk_full);
-        const int u0 = sk_w * p.sk_q;
-        const int u1 = min(p.sk_units, u0 + p.sk_q);
-        tile = p.sk_full + u0 / chunks;
-        c_begin = u0 - (u0 / chunks) * chunks;
-        c_end = min(chunks, c_begin + (u1 - u0));
-        seg1_len = (u1 - u0) - (c_end - c_begin);
-        nseg = seg1_len > 0 ? 2 : 1;
-        to_slab = true;
+        role = OWNER;
+        tile = p.sk_full + xcd_contiguous(blockIdx.x - p.sk_full - p.sk_helpers, p.sk_rem);
+        c_end = p.sk_owner_chunks;
     }
+    unsigned* const sk_counters = reinterpret_cast<unsigned*>(p.slabs + SK_SLAB_FLOATS);
 
-    for (int seg = 0; seg < nseg; ++seg) {
-        if (seg == 1) { tile += 1; c_begin = 0; c_end = seg1_len; }
+    do {
+        int part = 0;
+        if (role == HELPER) {                               // next segment of this helper's run
+            const int r = hu / Kh, off = hu - r * Kh;
+            const int len = min(Kh - off, hu_end - hu);
+            tile = p.sk_full + r;
+            c_begin = p.sk_owner_chunks + off; c_end = c_begin + len;
+            part = helper_id - (r * Kh) / p.sk_q;           // position among the helpers that touch this tile
+            hu += len;
+        }
         const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -349,10 +367,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
             }
         }
 
-        if (!to_slab) {
-            conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
-        } else {
-            float* __restrict__ slab = p.slabs + ((size_t)sk_w * 2 + seg) * TL::SLAB;
+        if (role == HELPER) {
+            const int r = tile - p.sk_full;
+            float* __restrict__ slab = p.slabs + ((size_t)r * p.sk_maxp + part) * TL::SLAB;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -362,12 +379,50 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                         v4f v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                         *reinterpret_cast<v4f*>(slab + ((size_t)((i * TN + j) * 4 + g) * TL::T + tid) * 4) = v;
                     }
+            if (p.sk_owner_chunks > 0) {
+                // publish (cdna_hip_programming.md Guideline 16, counter form): every wave drains its stores,
+                // barrier, ONE lane releases at agent scope, waits, then bumps the tile's counter
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(sk_counters + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            continue;
         }
-    }
+        if (role == OWNER) {
+            const int r = tile - p.sk_full;
+            const int nparts = ((r + 1) * Kh - 1) / p.sk_q - (r * Kh) / p.sk_q + 1;
+            if (tid == 0) {                                 // ONE lane polls relaxed, then ONE acquire
+                while (__hip_atomic_load(sk_counters + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)nparts)
+                    __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(sk_counters + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            __syncthreads();
+            for (int q = 0; q < nparts; ++q) {              // K order: own chunks first, then the helpers' runs
+                const float* slab = p.slabs + ((size_t)r * p.sk_maxp + q) * TL::SLAB;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const v4f v = *reinterpret_cast<const v4f*>(slab + ((size_t)((i * TN + j) * 4 + g) * TL::T + tid) * 4);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[i][j][4 * g + c] += v[c];
+                        }
+            }
+        }
+        conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+    } while (role == HELPER && hu < hu_end);
 }
 
-// Sums the slabs of one stream-K tile in K order and applies the epilogue.  One workgroup per
-// (tile, 32x32 accumulator block of each wave): TM*TN times more workgroups than tiles, because this
+// Owner-less form: sums the slabs of one remainder tile in K order and applies the epilogue.  One workgroup
+// per (tile, 32x32 accumulator block of each wave): TM*TN times more workgroups than tiles, because this
 // kernel is pure streaming and R < #CUs*2 tiles alone would leave most of the chip's load queues empty.
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs p, const int tiles_n, const int chunks) {
@@ -379,8 +434,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs
     const int sub = blockIdx.x - r * (TM * TN);
     const int si = sub / TN, sj = sub - si * TN;
     const int tile = p.sk_full + r;
-    const int ub = r * chunks, ue = ub + chunks;        // this tile's unit range
-    const int w_first = ub / p.sk_q, w_last = (ue - 1) / p.sk_q;
+    const int nparts = ((r + 1) * chunks - 1) / p.sk_q - (r * chunks) / p.sk_q + 1;
     v16f acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -391,9 +445,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs
     v16f sum;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sum[e] = 0.f;
-    for (int w = w_first; w <= w_last; ++w) {
-        const int seg = (w * p.sk_q >= ub) ? 0 : 1;     // a workgroup's 2nd segment is the tile it spills into
-        const float* __restrict__ slab = p.slabs + ((size_t)w * 2 + seg) * TL::SLAB;
+    for (int q = 0; q < nparts; ++q) {
+        const float* __restrict__ slab = p.slabs + ((size_t)r * p.sk_maxp + q) * TL::SLAB;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const v4f v = *reinterpret_cast<const v4f*>(slab + ((size_t)((si * TN + sj) * 4 + g) * TL::T + tid) * 4);
@@ -451,7 +504,17 @@ const float* conv_zero_line() {                      // 8 KiB of zeros: a padded
     return g_zeros;
 }
 
-size_t conv_slab_floats() { return (size_t)2 * 1280 * 128 * 128; }   // 2 segments x (<= 1280 stream-K workgroups) x largest tile
+size_t conv_slab_floats() { return SK_SLAB_FLOATS + SK_COUNTERS; }   // slabs + one counter word per remainder tile
+void conv_workspace_init(float* ws) { (void)hipMemset(ws + SK_SLAB_FLOATS, 0, SK_COUNTERS * sizeof(unsigned)); }
+
+static int g_sk_margin2 = -1;                         // helpers' head start over the owners, in half chunks
+static int sk_margin2() {
+    if (g_sk_margin2 < 0) {
+        const char* e = getenv("FACEHIP_SK_MARGIN");      // tuning hook
+        g_sk_margin2 = e ? atoi(e) : 3;
+    }
+    return g_sk_margin2;
+}
 
 template <int BM, int BN, int WM, int WN, int OCC>
 static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t s) {
@@ -463,33 +526,51 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
     a.zeros = conv_zero_line();
     int full = (T / S) * S;
     int R = T - full;
-    int sk_wgs = 0;
-    a.sk_units = 0; a.sk_q = 1;
+    int helpers = 0, owners = 0;
+    bool fixup = false;
+    a.sk_units = 0; a.sk_q = 1; a.sk_owner_chunks = 0; a.sk_maxp = 1;
     if (R > 0 && R * 10 <= S * 9 && a.slabs && a.sk_enable) {   // worth it only if the last round is <= 90 % full
-        const long U = (long)R * chunks;
-        int q = (int)((U + S - 1) / S);
-        const int min_q = chunks < 8 ? chunks : 8;          // do not cut segments shorter than 8 chunks
-        if (q < min_q) q = min_q;
-        sk_wgs = (int)((U + q - 1) / q);
-        if (q >= chunks || (size_t)sk_wgs * 2 * BM * BN > conv_slab_floats()) {
-            sk_wgs = 0;                                     // whole tiles per workgroup anyway: plain tiles
-        } else {
-            a.sk_units = (int)U; a.sk_q = q;
+        // (1) owners + helpers inside the launch
+        const int H = S - R;
+        const int q_o = (int)(((long)R * chunks + (long)H * sk_margin2() / 2 + S - 1) / S);
+        const int Kh = chunks - q_o;
+        if (Kh >= 1 && q_o >= 1 && R <= (int)SK_COUNTERS) {
+            const long U = (long)R * Kh;
+            const int q_h = (int)((U + H - 1) / H);
+            const int maxp = (Kh + q_h - 1) / q_h + 1;
+            if (maxp <= 3 && (size_t)R * maxp * BM * BN <= SK_SLAB_FLOATS) {
+                a.sk_units = (int)U; a.sk_q = q_h; a.sk_owner_chunks = q_o; a.sk_maxp = maxp;
+                helpers = (int)((U + q_h - 1) / q_h); owners = R;
+            }
+        }
+        // (2) otherwise: every segment to a slab, reduced by the fix-up kernel
+        if (!owners) {
+            const long U = (long)R * chunks;
+            int q = (int)((U + S - 1) / S);
+            const int min_q = chunks < 8 ? chunks : 8;          // do not cut segments shorter than 8 chunks
+            if (q < min_q) q = min_q;
+            const int maxp = (chunks + q - 1) / q + 1;
+            if (q < chunks && (size_t)R * maxp * BM * BN <= SK_SLAB_FLOATS) {
+                a.sk_units = (int)U; a.sk_q = q; a.sk_maxp = maxp;
+                helpers = (int)((U + q - 1) / q); fixup = true;
+            }
         }
     }
-    if (sk_wgs == 0) { full = T; R = 0; }
-    a.sk_full = full;
+    if (!helpers) { full = T; R = 0; }
+    a.sk_full = full; a.sk_helpers = helpers; a.sk_rem = R;
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
+    const dim3 grid((unsigned)(full + helpers + owners));
     if ((a.Cin & 31) == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true>), dim3((unsigned)(full + sk_wgs)), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, false>), dim3((unsigned)(full + sk_wgs)), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, false>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
     timer.end(s, cfg_tag, a.t_flops, a.t_bytes);
-    if (sk_wgs > 0) timer.begin(s);
-    if (sk_wgs > 0)
+    if (fixup) {
+        timer.begin(s);
         hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, WM, WN>), dim3((unsigned)(R * (BM / WM / 32) * (BN / WN / 32))), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
-    if (sk_wgs > 0) timer.end(s, 6, 0.0, 0.0);
+        timer.end(s, 6, 0.0, 0.0);
+    }
 }
 
 void launch_conv(const ConvArgs& a, int cfg, hipStream_t s) {

@@ -128,7 +128,10 @@ void Net::reserve(int max_batch) {
     if (max_batch <= cap_) return;
     cap_ = max_batch;
     arena_.ensure(plan_.arena_elems * (size_t)cap_ * sizeof(float));
-    partial_.ensure(conv_slab_floats() * sizeof(float));
+    if (partial_.bytes < conv_slab_floats() * sizeof(float)) {
+        partial_.ensure(conv_slab_floats() * sizeof(float));
+        conv_workspace_init(partial_.as<float>());
+    }
     // the 4th input lane and alignment gaps must never hold NaNs
     FH_HIP(hipMemset(arena_.p, 0, arena_.bytes));
 }

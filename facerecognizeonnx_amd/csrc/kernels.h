@@ -63,12 +63,15 @@ struct ConvArgs {
     int oact[3];
     int sk_enable;          // allow the stream-K remainder wave
     double t_flops, t_bytes; // algorithmic work of this launch (only used by the optional KernelTimer)
-    int sk_full, sk_units, sk_q;   // filled in by launch_conv: #plain tiles, remainder K-chunks, chunks per stream-K workgroup
+    // filled in by launch_conv: #plain tiles, K-chunk units dealt to helpers, units per helper, #helpers, #remainder
+    // tiles, chunks each owner computes itself (0 = no owners: fix-up kernel), slab slots per remainder tile
+    int sk_full, sk_units, sk_q, sk_helpers, sk_rem, sk_owner_chunks, sk_maxp;
 };
 
 // cfg: 0 = 128x128 tile, 1 = 256x64, 2 = 128x32, 3 = 64x64 (256 threads each); -1 = choose.
 void launch_conv(const ConvArgs& a, int cfg, hipStream_t s);
 int conv_pick_cfg(long M, int Cout);
+void conv_workspace_init(float* ws);          // zero the counter words of a freshly allocated stream-K workspace
 const float* conv_zero_line();                // 8 KiB of device zeros (target of padded / dead loads)
 // depthwise 3x3 stride 1 (+bias +act) fused with the 1x1 conv that consumes it (dwpw_mfma.hip)
 void launch_dwpw(const ConvArgs& a, hipStream_t s);

@@ -382,14 +382,15 @@ def test_cpp_shim_matches_python_api(models_dir, tmp_path):
     assert bad.returncode != 0 and "Error loading face detector model" in bad.stderr
 
 
-def test_streamk_is_deterministic_and_matches_plain_tiles():
-    """Stream-K remainder wave + slab fix-up: bit-identical from run to run, and equal to the plain one-tile-per-
-    workgroup schedule up to fp32 summation order (K is cut at different places)."""
+@pytest.mark.parametrize("n", [37, 96, 128])
+def test_streamk_is_deterministic_and_matches_plain_tiles(n):
+    """Stream-K remainder round (owner/helper hand-off inside the launch, or slabs + fix-up kernel for the FC):
+    bit-identical from run to run, and equal to the plain one-tile-per-workgroup schedule up to fp32 summation
+    order (K is cut at different places).  Ragged batch sizes: no stage has a whole number of tile rounds."""
     from facerecognizeonnx_amd.synth import models
     path = models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
     rec = fa.FaceRecognizer()
     assert rec.loadModel(path)
-    n = 96                                                  # ragged: no stage has a whole number of tile rounds
     crops = dev(util.frames_u8(n, 112, 112, seed=12))
     res = {}
     for mode in (1, 0, 1, 1):
