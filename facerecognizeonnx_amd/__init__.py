@@ -5,8 +5,8 @@ FaceRecognizer::extractFeature / compareFaces) behind a C ABI (include/facehip.h
 as hand-written gfx950 HIP kernels (csrc/).  See DESIGN.md.
 """
 from .api import (FaceBox, FaceDetector, FaceRecognizer, Gallery, pipeline_run_dev, pipeline_submit_dev,  # noqa: F401
-                  plan_describe)
+                  imread, plan_describe)
 from ._lib import FACE_DTYPE, FaceHipError, build, lib  # noqa: F401
 
-__all__ = ["FaceBox", "FaceDetector", "FaceRecognizer", "Gallery", "pipeline_run_dev", "pipeline_submit_dev", "plan_describe",
+__all__ = ["FaceBox", "FaceDetector", "FaceRecognizer", "Gallery", "pipeline_run_dev", "pipeline_submit_dev", "plan_describe", "imread",
            "FACE_DTYPE", "FaceHipError", "build", "lib"]

@@ -225,3 +225,16 @@ def plan_describe(path: str, default_h: int, default_w: int) -> str:
     buf = C.create_string_buffer(1 << 18)
     check(_lib.lib().fh_plan_describe(str(path).encode(), default_h, default_w, buf, len(buf)), "fh_plan_describe")
     return buf.value.decode()
+
+
+def imread(path: str) -> Optional[np.ndarray]:
+    """cv::imread(path) (reference src/main.cpp:42): BGR u8 [rows, cols, 3], or None when the file cannot be read or
+    decoded (cv::imread returns an empty Mat).  JPEG / PNG / BMP / PPM, decoded by the library's own host code."""
+    L = _lib.lib()
+    p, r, c = C.c_void_p(), C.c_int(), C.c_int()
+    if L.fh_imread(str(path).encode(), C.byref(p), C.byref(r), C.byref(c)) != 0:
+        return None
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), (r.value, c.value, 3)).copy()
+    finally:
+        L.fh_image_free(p)

@@ -6,8 +6,8 @@
 
 Same flows as testDetection / testRecognition / testRecognitionSimple (main.cpp:39-199) — detect, take
 faces[0] of each image, extractFeature, compareFaces, threshold 0.6 — but boxes / scores / similarity
-are printed instead of drawn (no GUI, no webcam), and images are read with PIL (RGB -> BGR) or from
-`.npy` arrays of shape [rows, cols, 3] (BGR u8), since OpenCV's imread is not available here.
+are printed instead of drawn (no GUI, no webcam).  Images are read by the library's own cv::imread replacement
+(fh_imread: JPEG / PNG / BMP / PPM -> BGR u8) or from `.npy` arrays of shape [rows, cols, 3] (BGR u8).
 Model paths default to the reference's (models/det_500m.onnx, models/w600k_r50.onnx, main.cpp:269-270).
 """
 from __future__ import annotations
@@ -17,14 +17,14 @@ import sys
 
 import numpy as np
 
+from . import api
 from .api import FaceDetector, FaceRecognizer
 
 
-def imread(path: str) -> np.ndarray:
+def imread(path: str):
     if path.endswith(".npy"):
         return np.ascontiguousarray(np.load(path), np.uint8)
-    from PIL import Image
-    return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    return api.imread(path)
 
 
 def main(argv=None) -> int:
@@ -44,6 +44,10 @@ def main(argv=None) -> int:
         print("Failed to load face recognizer model", file=sys.stderr)         # main.cpp:280-284
         return -1
     imgs = [imread(p) for p in a.images]
+    for p, im in zip(a.images, imgs):
+        if im is None:
+            print(f"Cannot read image: {p}", file=sys.stderr)                   # main.cpp:43-46
+            return -1
     if a.mode == "detect":                                                     # main.cpp:39-65
         faces = det.detect(imgs[0], a.score, a.nms)
         print(f"Detected {len(faces)} faces")

@@ -29,6 +29,10 @@ int arg_error(const char* msg) { g_err = msg; return FH_ERR_ARG; }
 hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 }  // namespace
 
+namespace fh {
+void set_error(const std::string& msg) { g_err = msg; }      // for the other translation units of the C ABI
+}
+
 struct fh_det {
     explicit fh_det(const char* p) : det(p) {}
     fh::Detector det;

@@ -5,11 +5,18 @@
 #pragma once
 #if defined(FACEHIP_USE_OPENCV)
 #include <opencv2/core.hpp>
+#include <opencv2/imgcodecs.hpp>
 #else
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <string>
+
+extern "C" {                                          // include/facehip.h (libfacehip.so)
+int fh_imread(const char* path, unsigned char** bgr, int* rows, int* cols);
+void fh_image_free(unsigned char* bgr);
+}
 
 #ifndef CV_8UC3
 #define CV_8UC3 16
@@ -59,6 +66,18 @@ class Mat {
   private:
     std::shared_ptr<uint8_t[]> own_;
 };
+
+// cv::imread(path) with its default flag (IMREAD_COLOR): 8-bit BGR, or an empty Mat when the file cannot be read /
+// decoded.  Decoding is the library's own host code (csrc/image_io.cpp: JPEG, PNG, BMP, PPM).
+inline Mat imread(const std::string& path) {
+    unsigned char* p = nullptr;
+    int r = 0, c = 0;
+    if (fh_imread(path.c_str(), &p, &r, &c) != 0 || !p) return Mat();
+    Mat m(r, c, CV_8UC3);
+    std::memcpy(m.data, p, (size_t)r * c * 3);
+    fh_image_free(p);
+    return m;
+}
 
 }  // namespace cv
 #endif

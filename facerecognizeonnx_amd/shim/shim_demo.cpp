@@ -1,31 +1,24 @@
 // shim_demo.cpp — the reference's `compare` flow (src/main.cpp:67-134: detect on two images,
 // extractFeature of faces[0] of each, compareFaces, threshold 0.6) written against the drop-in
-// headers, with raw BGR files instead of cv::imread (no image codecs in this image) and text
-// output instead of cv::imshow.   usage: shim_demo det.onnx rec.onnx a.bgr rows cols b.bgr rows cols [thr]
+// headers: cv::imread -> detect -> extractFeature -> compareFaces, with text output instead of cv::imshow.
+// usage: shim_demo det.onnx rec.onnx image1 image2 [score_thr]        (JPEG / PNG / BMP / PPM)
 #include <cstdio>
 #include <cstdlib>
-#include <fstream>
 #include <iostream>
 #include <vector>
 
 #include "face_detector.h"
 #include "face_recognizer.h"
 
-static std::vector<unsigned char> slurp(const char* p) {
-    std::ifstream f(p, std::ios::binary);
-    return std::vector<unsigned char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-}
-
 int main(int argc, char** argv) {
-    if (argc < 9) { std::cerr << "usage: shim_demo det.onnx rec.onnx a.bgr rows cols b.bgr rows cols [score_thr]\n"; return 2; }
-    const float thr = argc > 9 ? (float)atof(argv[9]) : 0.5f;
+    if (argc < 5) { std::cerr << "usage: shim_demo det.onnx rec.onnx image1 image2 [score_thr]\n"; return 2; }
+    const float thr = argc > 5 ? (float)atof(argv[5]) : 0.5f;
     FaceDetector detector;
     if (!detector.loadModel(argv[1])) return -1;                       // main.cpp:274-278
     FaceRecognizer recognizer;
     if (!recognizer.loadModel(argv[2])) return -1;                     // main.cpp:280-284
-    auto da = slurp(argv[3]), db = slurp(argv[6]);
-    cv::Mat a(atoi(argv[4]), atoi(argv[5]), CV_8UC3, da.data()), b(atoi(argv[7]), atoi(argv[8]), CV_8UC3, db.data());
-    if (da.size() != (size_t)a.rows * a.cols * 3 || db.size() != (size_t)b.rows * b.cols * 3) { std::cerr << "bad image size\n"; return -1; }
+    cv::Mat a = cv::imread(argv[3]), b = cv::imread(argv[4]);          // main.cpp:71-72
+    if (a.empty() || b.empty()) { std::cerr << "Cannot read image" << std::endl; return -1; }   // main.cpp:74-77
     auto fa = detector.detect(a, thr), fb = detector.detect(b, thr);   // main.cpp:88-89
     printf("faces %zu %zu\n", fa.size(), fb.size());
     if (fa.empty() || fb.empty()) return 0;

@@ -151,6 +151,14 @@ FH_API int fh_rec_set_conv_cfg(fh_rec* r, int cfg, int stream_k);
 FH_API int fh_det_set_fused_stem(fh_det* d, int on);
 FH_API int fh_rec_set_fused_stem(fh_rec* r, int on);
 
+/* ---- image files -> BGR u8, replaces cv::imread(path) (reference src/main.cpp:42,71-72,140-141; OpenCV's default
+ * IMREAD_COLOR: 8-bit BGR, alpha dropped, grey replicated, JPEG EXIF orientation applied).  Host code.  JPEG
+ * (baseline + progressive; libjpeg's islow IDCT / fancy up-sampling / YCbCr tables restated), PNG, BMP, PPM/PGM.
+ * *bgr is malloc'ed [rows*cols*3], release it with fh_image_free.  0 on success, < 0 + fh_last_error(). */
+FH_API int fh_imread(const char* path, unsigned char** bgr, int* rows, int* cols);
+FH_API int fh_image_decode(const unsigned char* bytes, size_t n, unsigned char** bgr, int* rows, int* cols);
+FH_API void fh_image_free(unsigned char* bgr);
+
 /* ---- single kernels exposed for parity tests and micro-benchmarks (device pointers). */
 FH_API int fh_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);   /* synchronous */
 FH_API int fh_resize_u8c3_dev(const uint8_t* d_src, int sh, int sw, int sstep, uint8_t* d_dst, int dh, int dw, int dstep,

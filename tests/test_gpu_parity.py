@@ -180,6 +180,23 @@ def test_detect_host_api_matches_oracle_end_to_end(models_dir):
     assert len(det.detect_records(np.zeros((0, 0, 3), np.uint8))) == 0
 
 
+def test_c1_single_jpeg_detect_matches_oracle():
+    """BASELINE.json configs[0]: one 640x640 JPEG -> imread -> det_500m detect (full-size synthetic graph)."""
+    from facerecognizeonnx_amd.synth import models
+    path = models.cached("det_500m_seed100.onnx", models.make_det_500m)
+    img = fa.imread(os.path.join(os.path.dirname(__file__), "golden", "images", "c1_640x640.jpg"))
+    assert img is not None and img.shape == (640, 640, 3)
+    det = fa.FaceDetector(); odet = oracle.OracleDetector()
+    assert det.loadModel(path) and odet.loadModel(path)
+    got = det.detect_records(img, 0.5, 0.4)
+    ref = odet.detect(img, 0.5, 0.4)
+    assert len(ref) > 0 and abs(len(got) - len(ref)) <= max(2, len(ref) // 50)      # scores within 1e-6 of the threshold may flip
+    n = min(len(got), len(ref), 5)
+    for k in ("x", "y", "w", "h"):
+        assert np.abs(got[k][:n].astype(int) - ref[k][:n].astype(int)).max() <= 1
+    np.testing.assert_allclose(got["score"][:n], ref["score"][:n], atol=1e-4)
+
+
 def test_predecoded_layout_bit_exact(models_dir):
     from facerecognizeonnx_amd.synth import models
     for three_d in (True, False):
@@ -362,9 +379,9 @@ def test_cpp_shim_matches_python_api(models_dir, tmp_path):
     dpath = util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0)
     rpath = util.tiny_iresnet(models_dir)
     imgs = util.frames_u8(2, 120, 160, seed=77, smooth=True)
-    pa, pb = str(tmp_path / "a.bgr"), str(tmp_path / "b.bgr")
-    imgs[0].tofile(pa); imgs[1].tofile(pb)
-    out = subprocess.run([exe, dpath, rpath, pa, "120", "160", pb, "120", "160", "0.5"], capture_output=True, text=True, timeout=120)
+    pa, pb = str(tmp_path / "a.ppm"), str(tmp_path / "b.bmp")             # read back by the shim's cv::imread
+    util.write_ppm(pa, imgs[0]); util.write_bmp(pb, imgs[1])
+    out = subprocess.run([exe, dpath, rpath, pa, pb, "0.5"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
     det = fa.FaceDetector(); rec = fa.FaceRecognizer()
@@ -378,8 +395,10 @@ def test_cpp_shim_matches_python_api(models_dir, tmp_path):
     assert abs(float(lines["self"]) - 1.0) < 1e-5
     np.testing.assert_allclose([float(v) for v in lines["f1"].split()], f1[:8], atol=2e-6)
     # reference error behaviour through the shim: bad model path -> loadModel false -> exit code -1
-    bad = subprocess.run([exe, "/nonexistent.onnx", rpath, pa, "120", "160", pb, "120", "160"], capture_output=True, text=True)
+    bad = subprocess.run([exe, "/nonexistent.onnx", rpath, pa, pb], capture_output=True, text=True)
     assert bad.returncode != 0 and "Error loading face detector model" in bad.stderr
+    bad = subprocess.run([exe, dpath, rpath, str(tmp_path / "missing.jpg"), pb], capture_output=True, text=True)
+    assert bad.returncode != 0 and "Cannot read image" in bad.stderr
 
 
 @pytest.mark.parametrize("n", [37, 96, 128])
@@ -414,8 +433,8 @@ def test_cli_modes(models_dir, tmp_path, capsys):
     dpath = util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0)
     rpath = util.tiny_iresnet(models_dir)
     imgs = util.frames_u8(2, 120, 160, seed=77, smooth=True)
-    pa, pb = str(tmp_path / "a.npy"), str(tmp_path / "b.npy")
-    np.save(pa, imgs[0]); np.save(pb, imgs[1])
+    pa, pb = str(tmp_path / "a.ppm"), str(tmp_path / "b.npy")
+    util.write_ppm(pa, imgs[0]); np.save(pb, imgs[1])
     assert cli.main(["detect", pa, "--det", dpath]) == 0
     out = capsys.readouterr().out
     det = fa.FaceDetector(); assert det.loadModel(dpath)
@@ -426,6 +445,7 @@ def test_cli_modes(models_dir, tmp_path, capsys):
     assert cli.main(["simple", pa, pa, "--rec", rpath]) == 0
     assert "Same person" in capsys.readouterr().out                       # identical images -> similarity 1
     assert cli.main(["detect", pa, "--det", str(tmp_path / "missing.onnx")]) == -1
+    assert cli.main(["detect", str(tmp_path / "missing.jpg"), "--det", dpath]) == -1
 
 
 def test_async_two_stream_pipeline_equals_serial(models_dir):

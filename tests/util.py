@@ -51,3 +51,23 @@ def random_landmarks(n, rows, cols, seed=3, jitter=1.0):
         t = np.array([rng.uniform(0, max(1, cols - 112 * s)), rng.uniform(0, max(1, rows - 112 * s))])
         out[i] = (TEMPLATE @ R.T + t + rng.normal(0, jitter, (5, 2))).astype(np.float32)
     return out
+
+
+def write_ppm(path, bgr):
+    """Binary PPM (P6, RGB order) of a BGR u8 image."""
+    h, w, _ = bgr.shape
+    with open(path, "wb") as f:
+        f.write(f"P6\n{w} {h}\n255\n".encode())
+        f.write(np.ascontiguousarray(bgr[:, :, ::-1]).tobytes())
+
+
+def write_bmp(path, bgr):
+    """24-bit bottom-up BMP of a BGR u8 image."""
+    import struct
+    h, w, _ = bgr.shape
+    stride = (w * 3 + 3) & ~3
+    rows = b"".join(bgr[y].tobytes() + b"\0" * (stride - w * 3) for y in range(h - 1, -1, -1))
+    with open(path, "wb") as f:
+        f.write(b"BM" + struct.pack("<IHHI", 54 + len(rows), 0, 0, 54))
+        f.write(struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, len(rows), 2835, 2835, 0, 0))
+        f.write(rows)
