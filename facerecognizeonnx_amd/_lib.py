@@ -74,6 +74,9 @@ PROTOTYPES = {
     "fh_gallery_create": (_vp, [_i]),
     "fh_gallery_destroy": (None, [_vp]),
     "fh_gallery_upload": (_i, [_vp, _vp, _ll, _i, _ll]),
+    "fh_gallery_enroll": (_ll, [_vp, _vp, _ll, _i]),
+    "fh_gallery_size": (_ll, [_vp]),
+    "fh_gallery_label_dev": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "fh_gallery_topk_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "fh_timing_enable": (_i, [_i]),
     "fh_timing_collect": (_i, [_vp, _vp, _vp, _vp, _i]),

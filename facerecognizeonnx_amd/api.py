@@ -220,6 +220,19 @@ class Gallery:
     def topk_dev(self, q_ptr: int, nq: int, k: int, scores_ptr: int, idx_ptr: int, stream: int = 0):
         check(_lib.lib().fh_gallery_topk_dev(self._h, q_ptr, nq, k, scores_ptr, idx_ptr, stream), "fh_gallery_topk_dev")
 
+    def enroll(self, rows) -> int:
+        """Append L2-normalised feature rows (host array [n, dim]); the webcam loop's 's' key (main.cpp:253-256).
+        Returns the index of the first new row."""
+        rows = np.ascontiguousarray(rows, np.float32).reshape(-1, self.dim)
+        return check(_lib.lib().fh_gallery_enroll(self._h, rows.ctypes.data, rows.shape[0], 0), "fh_gallery_enroll")
+
+    def __len__(self) -> int:
+        return int(_lib.lib().fh_gallery_size(self._h))
+
+    def label_dev(self, q_ptr: int, nq: int, threshold: float, labels_ptr: int, scores_ptr: int, stream: int = 0):
+        """labels[q] = best row if (dot+1)/2 > threshold else -1 ("Match" / "Unknown", main.cpp:229-233)."""
+        check(_lib.lib().fh_gallery_label_dev(self._h, q_ptr, nq, threshold, labels_ptr, scores_ptr, stream), "fh_gallery_label_dev")
+
 
 def plan_describe(path: str, default_h: int, default_w: int) -> str:
     buf = C.create_string_buffer(1 << 18)

@@ -305,6 +305,17 @@ int fh_gallery_upload(fh_gallery* g, const float* rows, long long n, int on_devi
     if (!g || !rows || n <= 0) return arg_error("fh_gallery_upload: bad argument");
     return guarded([&] { g->g.upload(rows, (long)n, on_device != 0, (long)index_base); return 0; });
 }
+long long fh_gallery_enroll(fh_gallery* g, const float* rows, long long n, int on_device) {
+    if (!g || !rows || n <= 0) return arg_error("fh_gallery_enroll: bad argument");
+    long long first = -1;
+    const int rc = guarded([&] { first = g->g.enroll(rows, (long)n, on_device != 0); return 0; });
+    return rc < 0 ? rc : first;
+}
+long long fh_gallery_size(fh_gallery* g) { return g ? (long long)g->g.size() : (long long)arg_error("fh_gallery_size: null handle"); }
+int fh_gallery_label_dev(fh_gallery* g, const float* q, int nq, float threshold, int* labels, float* scores, void* stream) {
+    if (!g || !q || !labels || !scores) return arg_error("fh_gallery_label_dev: null argument");
+    return guarded([&] { g->g.label_dev(q, nq, threshold, labels, scores, S(stream)); return nq; });
+}
 int fh_gallery_topk_dev(fh_gallery* g, const float* q, int nq, int k, float* scores, int* indices, void* stream) {
     if (!g || !q || !scores || !indices) return arg_error("fh_gallery_topk_dev: null argument");
     return guarded([&] { g->g.topk_dev(q, nq, k, scores, indices, S(stream)); return nq; });

@@ -363,6 +363,30 @@ void Gallery::upload(const float* rows, long n, bool device_src, long index_base
     n_ = n; base_ = index_base;
 }
 
+long Gallery::enroll(const float* rows, long n, bool device_src) {
+    if (dim_ % 32) throw std::runtime_error("gallery: dim must be a multiple of 32");
+    const size_t row_bytes = (size_t)dim_ * sizeof(float);
+    const size_t need = (size_t)(n_ + n) * row_bytes;
+    if (need > rows_.bytes) {                                    // grow geometrically, keeping the enrolled rows
+        DevBuf bigger;
+        bigger.ensure(std::max(need, rows_.bytes * 2));
+        if (n_ > 0) FH_HIP(hipMemcpy(bigger.p, rows_.p, (size_t)n_ * row_bytes, hipMemcpyDeviceToDevice));
+        std::swap(bigger.p, rows_.p);
+        std::swap(bigger.bytes, rows_.bytes);
+    }
+    FH_HIP(hipMemcpy(static_cast<char*>(rows_.p) + (size_t)n_ * row_bytes, rows, (size_t)n * row_bytes,
+                     device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    const long first = base_ + n_;
+    n_ += n;
+    return first;
+}
+
+void Gallery::label_dev(const float* q, int Q, float thr, int* out_label, float* out_score, hipStream_t s) {
+    best_i_.ensure((size_t)std::max(Q, 1) * sizeof(int));
+    topk_dev(q, Q, 1, out_score, best_i_.as<int>(), s);
+    launch_label(out_score, best_i_.as<int>(), Q, thr, out_label, s);
+}
+
 void Gallery::topk_dev(const float* q, int Q, int k, float* out_score, int* out_idx, hipStream_t s) {
     if (Q <= 0 || Q > 256 || k <= 0 || k > 16) throw std::runtime_error("gallery: need 0 < Q <= 256 and 0 < k <= 16");
     const long kSlab = 1L << 20;

@@ -111,6 +111,9 @@ class Gallery {
   public:
     explicit Gallery(int dim) : dim_(dim) {}
     void upload(const float* rows, long n, bool device_src, long index_base);
+    long enroll(const float* rows, long n, bool device_src);     // append; returns the global index of the first new row
+    // best row per query if its mapped score > thr, else -1 (main.cpp:229-233); out_score = that best score
+    void label_dev(const float* q, int Q, float thr, int* out_label, float* out_score, hipStream_t s);
     // queries [Q][dim] device, Q <= 256, k <= 16 -> out_score/out_idx [Q][k] device
     void topk_dev(const float* q, int Q, int k, float* out_score, int* out_idx, hipStream_t s);
     long size() const { return n_; }
@@ -119,7 +122,7 @@ class Gallery {
   private:
     int dim_;
     long n_ = 0, base_ = 0;
-    DevBuf rows_, qpack_, dots_, ps_, pi_;
+    DevBuf rows_, qpack_, dots_, ps_, pi_, best_i_;
 };
 
 }  // namespace fh

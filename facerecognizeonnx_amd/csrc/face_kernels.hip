@@ -533,6 +533,16 @@ void launch_topk_partial(const float* dots, long G, int Q, int k, float* part_sc
     hipLaunchKernelGGL(topk_partial_kernel, dim3(gallery_blocks(G)), dim3(256), 0, s, dots, G, Q, k, part_score, part_idx, idx_base);
 }
 
+// Match / Unknown decision of the reference's webcam loop (src/main.cpp:229-233): a query is labelled with its best
+// gallery row when the mapped score (dot+1)/2 is STRICTLY above the threshold, else -1.
+__global__ void label_kernel(const float* __restrict__ best_s, const int* __restrict__ best_i, int n, float thr, int* __restrict__ labels) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) labels[q] = (best_i[q] >= 0 && best_s[q] > thr) ? best_i[q] : -1;
+}
+void launch_label(const float* best_score, const int* best_idx, int n, float thr, int* labels, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(label_kernel, dim3((n + 255) / 256), dim3(256), 0, s, best_score, best_idx, n, thr, labels);
+}
+
 void launch_topk_merge(const float* part_score, const int* part_idx, int nparts, int Q, int k, float* out_score, int* out_idx,
                        hipStream_t s) {
     hipLaunchKernelGGL(topk_merge_kernel, dim3(Q), dim3(256), 0, s, part_score, part_idx, nparts, Q, k, out_score, out_idx);

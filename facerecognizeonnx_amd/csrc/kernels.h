@@ -148,6 +148,7 @@ void launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_
 // as GEMM-M, queries as GEMM-N); partial lists [gallery_blocks(G)*(256/Q)][Q][k] then one merge.
 void launch_topk_partial(const float* dots, long G, int Q, int k, float* part_score, int* part_idx, long idx_base,
                          hipStream_t s);
+void launch_label(const float* best_score, const int* best_idx, int n, float thr, int* labels, hipStream_t s);
 void launch_topk_merge(const float* part_score, const int* part_idx, int nparts, int Q, int k, float* out_score,
                        int* out_idx, hipStream_t s);
 int gallery_blocks(long G);

@@ -134,6 +134,14 @@ FH_API void fh_gallery_destroy(fh_gallery* g);
 FH_API int fh_gallery_upload(fh_gallery* g, const float* rows, long long n, int rows_on_device, long long index_base);
 FH_API int fh_gallery_topk_dev(fh_gallery* g, const float* d_queries, int nq, int k, float* d_scores, int* d_indices,
                                void* stream);
+/* The webcam loop's reference handling (src/main.cpp:211-212,229-233,253-256) for an enrolled SET instead of one
+ * refFeature: enroll appends rows (the 's' key; returns the index of the first new row), label gives every query its
+ * best row when (dot+1)/2 > threshold ("Match", reference threshold 0.6, strict) and -1 otherwise ("Unknown");
+ * d_scores[q] = the best mapped score (-1 for an empty gallery). */
+FH_API long long fh_gallery_enroll(fh_gallery* g, const float* rows, long long n, int rows_on_device);
+FH_API long long fh_gallery_size(fh_gallery* g);
+FH_API int fh_gallery_label_dev(fh_gallery* g, const float* d_queries, int nq, float threshold, int* d_labels,
+                                float* d_scores, void* stream);
 
 /* ---- measurement hooks (bench.py): per-launch HIP-event timing of the network kernels.
  * Tags 0..3 = conv_igemm tile configs (128x128, 256x64, 128x32, 64x64), 4 = depthwise conv,

@@ -371,6 +371,37 @@ def test_pipeline_and_gallery(models_dir):
     assert list(ri[0][:2]) == [123, 4000]
 
 
+def test_gallery_enroll_and_match_labels():
+    """The webcam loop's reference handling (main.cpp:229-233,253-256) over an enrolled set: rows are appended one
+    call at a time, a query is a Match for its best row iff (dot+1)/2 > threshold (strict), else Unknown (-1)."""
+    rng = np.random.default_rng(9)
+    unit = lambda a: (a / np.linalg.norm(a, axis=-1, keepdims=True)).astype(np.float32)
+    feats = unit(rng.standard_normal((74, 512)))
+    q = unit(rng.standard_normal((6, 512)))
+    q[0] = feats[5]                                                        # same face: score 1.0
+    q[1] = unit(feats[40] + 0.9 * unit(rng.standard_normal(512)))          # cos ~ 0.74 -> mapped ~ 0.87: Match
+    q[2] = feats[73]                                                       # a row of the last enrol call
+    qd = dev(q)
+    lab = torch.full((6,), 7, dtype=torch.int32, device="cuda"); sc = torch.zeros(6, device="cuda")
+    g = fa.Gallery(512)
+    assert len(g) == 0
+    g.label_dev(qd.data_ptr(), 6, 0.6, lab.data_ptr(), sc.data_ptr()); torch.cuda.synchronize()
+    assert np.all(lab.cpu().numpy() == -1) and np.all(sc.cpu().numpy() == -1.0)          # nothing enrolled: all Unknown
+    assert g.enroll(feats[:1]) == 0 and g.enroll(feats[1:71]) == 1 and g.enroll(feats[71:]) == 71 and len(g) == 74
+    g.label_dev(qd.data_ptr(), 6, 0.6, lab.data_ptr(), sc.data_ptr()); torch.cuda.synchronize()
+    rs, ri = oracle.gallery_topk(q, feats, 1)
+    got_s, got_l = sc.cpu().numpy(), lab.cpu().numpy()
+    np.testing.assert_allclose(got_s, rs[:, 0], atol=2e-6)
+    assert list(got_l[:3]) == [5, 40, 73]
+    assert np.array_equal(got_l, np.where(got_s > np.float32(0.6), ri[:, 0], -1)) and np.any(got_l == -1)
+    # strictness: a threshold equal to the score itself is NOT a match, the next float below is
+    thr = float(got_s[1])
+    g.label_dev(qd.data_ptr(), 6, thr, lab.data_ptr(), sc.data_ptr()); torch.cuda.synchronize()
+    assert lab.cpu().numpy()[1] == -1
+    g.label_dev(qd.data_ptr(), 6, float(np.nextafter(np.float32(thr), np.float32(-1))), lab.data_ptr(), sc.data_ptr()); torch.cuda.synchronize()
+    assert lab.cpu().numpy()[1] == 40
+
+
 def test_cpp_shim_matches_python_api(models_dir, tmp_path):
     """The reference-shaped C++ classes (shim/face_detector.h, face_recognizer.h) run main.cpp's compare flow."""
     import subprocess
