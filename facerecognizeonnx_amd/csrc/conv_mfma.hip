@@ -522,7 +522,7 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (a.Cout + BN - 1) / BN;
     const int T = tiles_m * tiles_n;
     const int chunks = a.Kpad / 32;
-    const int S = num_cus() * resident_per_cu;
+    const int S = (a.cus > 0 ? a.cus : num_cus()) * resident_per_cu;
     a.zeros = conv_zero_line();
     int full = (T / S) * S;
     int R = T - full;

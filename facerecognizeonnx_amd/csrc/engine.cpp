@@ -182,6 +182,7 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 a.t2 = d.has_aff ? P + d.t2 : nullptr;
                 a.slabs = partial_.as<float>();
                 a.sk_enable = sk_enable ? 1 : 0;
+                a.cus = cus;
                 a.B = batch; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
                 a.ks = op.ks; a.stride = op.stride; a.pad = op.pad; a.Kpad = d.Kpad;
                 a.act = (int)op.act; a.res_mode = (int)op.res_mode;

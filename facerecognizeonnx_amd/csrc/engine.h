@@ -42,6 +42,7 @@ class Net {
     int in_h() const { return plan_.inH; }
     int in_w() const { return plan_.inW; }
     int capacity() const { return cap_; }
+    int cus = 0;                                          // CUs of the stream this net runs on when it is CU-masked (0 = all)
     int force_cfg = -1;                                   // tuning hook: conv tile config override
     bool sk_enable = true;                                // tuning hook: stream-K remainder wave
 

@@ -62,6 +62,7 @@ struct ConvArgs {
     int oc0[4];
     int oact[3];
     int sk_enable;          // allow the stream-K remainder wave
+    int cus;                // CUs this launch can occupy (0 = the whole device); sizes the stream-K remainder round
     double t_flops, t_bytes; // algorithmic work of this launch (only used by the optional KernelTimer)
     // filled in by launch_conv: #plain tiles, K-chunk units dealt to helpers, units per helper, #helpers, #remainder
     // tiles, chunks each owner computes itself (0 = no owners: fix-up kernel), slab slots per remainder tile

@@ -156,6 +156,11 @@ FH_API int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k);
 FH_API int fh_rec_set_conv_cfg(fh_rec* r, int cfg, int stream_k);
 /* on (default): the u8 preprocess is fused into the first convolution and the preprocessed input tensor is
  * never materialised; off: separate preprocess kernel (needed for fh_det_input_dev). */
+/* A handle whose stream is restricted to a subset of the CUs (hipExtStreamCreateWithCUMask, e.g. detector and
+ * recogniser side by side on disjoint CU sets) should say how many it gets: it sizes the convolution kernels'
+ * remainder round.  0 = the whole device (default). */
+FH_API int fh_det_set_cus(fh_det* d, int cus);
+FH_API int fh_rec_set_cus(fh_rec* r, int cus);
 FH_API int fh_det_set_fused_stem(fh_det* d, int on);
 FH_API int fh_rec_set_fused_stem(fh_rec* r, int on);
 

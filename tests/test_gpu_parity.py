@@ -458,6 +458,25 @@ def test_streamk_is_deterministic_and_matches_plain_tiles(n):
     assert (1.0 - cos).max() < 1e-6, (1.0 - cos).max()             # different K cut points: fp32 rounding only
 
 
+def test_remainder_round_for_any_slot_count():
+    """fh_rec_set_cus sizes the remainder round for a CU-masked stream; every slot count must give the same
+    embeddings up to fp32 summation order (and never dead-lock: helpers are always dispatched before owners)."""
+    from facerecognizeonnx_amd.synth import models
+    rec = fa.FaceRecognizer()
+    assert rec.loadModel(models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50))
+    n = 48
+    crops = dev(util.frames_u8(n, 112, 112, seed=13))
+    outs = []
+    for cus in (0, 255, 208, 100, 64, 9, 1):
+        assert fa.lib().fh_rec_set_cus(rec.handle, cus) == 0
+        out = torch.zeros((n, 512), device="cuda")
+        assert rec.embed_aligned_dev(crops.data_ptr(), n, out.data_ptr()) == n
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy().astype(np.float64))
+    for o in outs[1:]:
+        assert (1.0 - (o * outs[0]).sum(1)).max() < 1e-6
+
+
 def test_cli_modes(models_dir, tmp_path, capsys):
     """Text-mode counterpart of main.cpp's detect / compare / simple modes."""
     from facerecognizeonnx_amd import cli
