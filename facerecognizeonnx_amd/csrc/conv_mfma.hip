@@ -507,6 +507,19 @@ const float* conv_zero_line() {                      // 8 KiB of zeros: a padded
 size_t conv_slab_floats() { return SK_SLAB_FLOATS + SK_COUNTERS; }   // slabs + one counter word per remainder tile
 void conv_workspace_init(float* ws) { (void)hipMemset(ws + SK_SLAB_FLOATS, 0, SK_COUNTERS * sizeof(unsigned)); }
 
+static int sk_b_ratio() {                              // fix-up form only when a tile is cut into >= ratio/2 pieces (tuning hook)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FACEHIP_SK_B_RATIO"); v = e ? atoi(e) : 4; }
+    return v;
+}
+static int g_sk_min_owner = -1;
+static int sk_min_owner() {
+    if (g_sk_min_owner < 0) {
+        const char* e = getenv("FACEHIP_SK_MIN_OWNER");   // tuning hook
+        g_sk_min_owner = e ? atoi(e) : 12;
+    }
+    return g_sk_min_owner;
+}
 static int g_sk_margin2 = -1;                         // helpers' head start over the owners, in half chunks
 static int sk_margin2() {
     if (g_sk_margin2 < 0) {
@@ -534,7 +547,8 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
         const int H = S - R;
         const int q_o = (int)(((long)R * chunks + (long)H * sk_margin2() / 2 + S - 1) / S);
         const int Kh = chunks - q_o;
-        if (Kh >= 1 && q_o >= 1 && R <= (int)SK_COUNTERS) {
+        // (the hand-off costs an owner ~8 us — fence, poll, slab reads: only worth it next to >= 12 chunks of its own work)
+        if (Kh >= 1 && q_o >= sk_min_owner() && R <= (int)SK_COUNTERS) {
             const long U = (long)R * Kh;
             const int q_h = (int)((U + H - 1) / H);
             const int maxp = (Kh + q_h - 1) / q_h + 1;
@@ -550,7 +564,7 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
             const int min_q = chunks < 8 ? chunks : 8;          // do not cut segments shorter than 8 chunks
             if (q < min_q) q = min_q;
             const int maxp = (chunks + q - 1) / q + 1;
-            if (q < chunks && (size_t)R * maxp * BM * BN <= SK_SLAB_FLOATS) {
+            if (q * sk_b_ratio() <= chunks * 2 && q < chunks && (size_t)R * maxp * BM * BN <= SK_SLAB_FLOATS) {
                 a.sk_units = (int)U; a.sk_q = q; a.sk_maxp = maxp;
                 helpers = (int)((U + q - 1) / q); fixup = true;
             }

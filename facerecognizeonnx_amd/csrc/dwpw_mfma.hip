@@ -94,12 +94,15 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const in
 
     for (int kc = 0; kc < chunks; ++kc) {
         const int c0 = kc * 32;
-        const bool hvalid = c0 + hq * 4 < C;
+        const bool hvalid = c0 + hq * 4 < C;                               // 16-byte columns past C are never read: no DMA for them
+        const int ksteps = min(4, (C - c0 + 7) >> 3);                      // 8-deep MFMA steps that hold real channels
         __syncthreads();                                                   // previous chunk: halo + fragments fully consumed
+        if (hvalid) {
 #pragma unroll
-        for (int j = 0; j < HP; ++j) {
-            const float* src = (h_off[j] >= 0 && hvalid) ? img + h_off[j] + c0 : p.zeros;
-            dwpw_dma16(src, halo + j * 256 + wid * 64);
+            for (int j = 0; j < HP; ++j) {
+                const float* src = h_off[j] >= 0 ? img + h_off[j] + c0 : p.zeros;
+                dwpw_dma16(src, halo + j * 256 + wid * 64);
+            }
         }
 #pragma unroll
         for (int i = 0; i < BL; ++i) dwpw_dma16(reinterpret_cast<const float*>(w_base + w_off[i]), Wt + i * 256 + wid * 64);
@@ -112,26 +115,29 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const in
         for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const v4f*>(cvalid ? p.dw_w + (size_t)k * C + cw : p.zeros);
         b4 = *reinterpret_cast<const v4f*>(cvalid ? p.dw_b + cw : p.zeros);
         __syncthreads();                                                   // halo + weights landed (barrier drains vmcnt)
+        if (dq < 2 * ksteps) {
 #pragma unroll
-        for (int i = 0; i < BM / 32; ++i) {
-            const int px = dp + 32 * i;
-            const int py = px / DP_TW, pxx = px - py * DP_TW;
-            v4f a = b4;
+            for (int i = 0; i < BM / 32; ++i) {
+                const int px = dp + 32 * i;
+                const int py = px / DP_TW, pxx = px - py * DP_TW;
+                v4f a = b4;
+                if (cvalid) {                                              // (the invalid half of a partly valid step: zeros, its halo was not loaded)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+                    for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) a += halo[((py + ky) * DP_HW + pxx + kx) * 8 + dq] * wk[ky * 3 + kx];
-            if (p.dw_act == (int)Act::RELU) {
+                        for (int kx = 0; kx < 3; ++kx) a += halo[((py + ky) * DP_HW + pxx + kx) * 8 + dq] * wk[ky * 3 + kx];
+                    if (p.dw_act == (int)Act::RELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : 0.f;
+                        for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : 0.f;
+                    }
+                }
+                At[px * 8 + (dq ^ ((px >> 1) & 7))] = a;
             }
-            At[px * 8 + (dq ^ ((px >> 1) & 7))] = a;
         }
         __syncthreads();                                                   // A tile complete
         const v4f* X = At + (wm * TM * 32 + fr) * 8;
         const v4f* Wp = Wt + (wn * TN * 32 + fr) * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < ksteps; ++s) {
             const int col = (2 * s + fh2) ^ fsw;
             v4f x[TM], w[TN];
 #pragma unroll
@@ -203,6 +209,7 @@ void launch_dwpw(const ConvArgs& a0, hipStream_t s) {
     timer.begin(s);
     if (a.Cout <= 32) launch_dwpw_cfg<32, 4, 1>(a, s);
     else if (a.Cout <= 64) launch_dwpw_cfg<64, 2, 2>(a, s);
+    else if (a.Cout <= 96) launch_dwpw_cfg<96, 4, 1>(a, s);
     else launch_dwpw_cfg<128, 2, 2>(a, s);
     timer.end(s, 4, a.t_flops, a.t_bytes);
 }

@@ -76,6 +76,49 @@ def test_conv_layer_matches_oracle(B, H, W, Cin, Cout, k, stride, cfg):
     np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
 
 
+DWPW_CASES = [
+    # H,  W,  C, Cout     (H*W >= 1600 so that the planner fuses the pair; ragged tiles, channel counts off the 8/32 grid)
+    (40, 40, 16, 16),
+    (41, 53, 20, 72),
+    (48, 40, 40, 40),
+    (44, 60, 72, 96),
+    (40, 44, 36, 100),
+    (56, 40, 100, 24),
+]
+
+
+@pytest.mark.parametrize("H,W,Cc,Cout", DWPW_CASES)
+def test_depthwise_pointwise_block_matches_oracle(tmp_path, H, W, Cc, Cout):
+    """The fused depthwise 3x3 -> pointwise 1x1 kernel (dwpw_mfma.hip) on a three-conv graph, vs the oracle."""
+    from facerecognizeonnx_amd.synth.onnx_writer import OnnxBuilder
+    rng = np.random.default_rng(H * 100 + Cc)
+    b = OnnxBuilder("dwpw")
+    x = b.add_input("input", [1, 3, H, W])
+    def conv(x, w, bias, relu=True, **kw):
+        y = b.node("Conv", [x, b.init(b.uid("w"), w.astype(np.float32)), b.init(b.uid("b"), bias.astype(np.float32))], **kw)
+        return b.node("Relu", [y]) if relu else y
+    y = conv(x, rng.standard_normal((Cc, 3, 3, 3)) / 5, rng.standard_normal(Cc) / 10, kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[1, 1])
+    y = conv(y, rng.standard_normal((Cc, 1, 3, 3)) / 3, rng.standard_normal(Cc) / 10, kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[1, 1], group=Cc)
+    y = conv(y, rng.standard_normal((Cout, Cc, 1, 1)) / np.sqrt(Cc), rng.standard_normal(Cout) / 10, kernel_shape=[1, 1], strides=[1, 1])
+    y = b.node("Transpose", [y], perm=[0, 2, 3, 1])
+    b.node("Reshape", [y, b.init("shape", np.array([-1, Cout], np.int64))], outputs=["out"])
+    b.add_output("out", ["A", Cout])
+    path = b.save(str(tmp_path / "dwpw.onnx"))
+    assert "DW+PW" in fa.plan_describe(path, H, W)
+    det = fa.FaceDetector(); odet = oracle.OracleDetector()
+    assert det.loadModel(path) and odet.loadModel(path)
+    n = 2
+    frames = util.frames_u8(n, H, W, seed=Cout)
+    d = dev(frames)
+    assert fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), n, H, W, W * 3, H * W * 3, 0) == n
+    torch.cuda.synchronize()
+    got = _det_outputs(det, n)[0]
+    for i in range(n):
+        inp, _ = oracle.det_preprocess(frames[i], W, H)
+        ref = odet.run_network(inp)[0]
+        np.testing.assert_allclose(got[i], ref.reshape(got[i].shape), rtol=1e-5, atol=2e-5)
+
+
 def test_det_preprocess_bit_exact(models_dir):
     det = fa.FaceDetector()
     assert det.loadModel(util.tiny_scrfd(models_dir, hw=128))
