@@ -34,11 +34,14 @@ __device__ __forceinline__ void dwpw_dma16(const float* src, v4f* dst) {
 constexpr int DP_TH = 8, DP_TW = 16, DP_BM = DP_TH * DP_TW;            // 128 output pixels per tile
 constexpr int DP_HW = DP_TW + 2, DP_HALO = (DP_TH + 2) * DP_HW;         // 10 x 18 = 180 halo pixels
 
-template <int BN, int WM, int WN>
+// DS = stride of the depthwise part.  DS == 2 keeps no halo in LDS (a 17 x 33 halo would not fit beside the GEMM
+// tiles): every thread gathers the 9 taps of its outputs straight from global memory — each input pixel is
+// wanted by only 2.25 outputs on average and those re-reads hit L1 / L2.
+template <int BN, int WM, int WN, int DS>
 __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_n) {
     constexpr int BM = DP_BM;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int HALO_SLOTS = (DP_HALO * 8 + 255) / 256 * 256;           // float4 slots, whole DMA passes
+    constexpr int HALO_SLOTS = DS == 1 ? (DP_HALO * 8 + 255) / 256 * 256 : 0;   // float4 slots, whole DMA passes
     __shared__ v4f lds[HALO_SLOTS + BM * 8 + BN * 8];
     v4f* const halo = lds;
     v4f* const At = lds + HALO_SLOTS;
@@ -55,13 +58,13 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const in
     const int n = t / tiles_y;
     const int n0 = tile_n * BN;
     const int chunks = p.Kpad / 32;
-    const float* img = p.in + (size_t)n * p.H * p.W * C;                  // stride 1: H x W is also the output grid
+    const float* img = p.in + (size_t)n * p.H * p.W * C;                  // H x W = depthwise input, Ho x Wo = output grid
 
     // ---- halo loader: slot s = 256*j + tid covers halo pixel s>>3, 16-byte column s&7
-    constexpr int HP = HALO_SLOTS / 256;
+    constexpr int HP = DS == 1 ? HALO_SLOTS / 256 : 1;
     long h_off[HP];                                                        // float offset of (pixel, column 0) or -1
 #pragma unroll
-    for (int j = 0; j < HP; ++j) {
+    for (int j = 0; j < (DS == 1 ? HP : 0); ++j) {
         const int s = j * 256 + tid, hp = s >> 3;
         h_off[j] = -1;
         if (hp < DP_HALO) {
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const in
         const bool hvalid = c0 + hq * 4 < C;                               // 16-byte columns past C are never read: no DMA for them
         const int ksteps = min(4, (C - c0 + 7) >> 3);                      // 8-deep MFMA steps that hold real channels
         __syncthreads();                                                   // previous chunk: halo + fragments fully consumed
-        if (hvalid) {
+        if (DS == 1 && hvalid) {
 #pragma unroll
             for (int j = 0; j < HP; ++j) {
                 const float* src = h_off[j] >= 0 ? img + h_off[j] + c0 : p.zeros;
@@ -114,24 +117,55 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const in
 #pragma unroll
         for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const v4f*>(cvalid ? p.dw_w + (size_t)k * C + cw : p.zeros);
         b4 = *reinterpret_cast<const v4f*>(cvalid ? p.dw_b + cw : p.zeros);
-        __syncthreads();                                                   // halo + weights landed (barrier drains vmcnt)
-        if (dq < 2 * ksteps) {
+        if (DS == 1) {
+            __syncthreads();                                               // halo + weights landed (barrier drains vmcnt)
+            if (dq < 2 * ksteps) {
 #pragma unroll
-            for (int i = 0; i < BM / 32; ++i) {
-                const int px = dp + 32 * i;
-                const int py = px / DP_TW, pxx = px - py * DP_TW;
-                v4f a = b4;
-                if (cvalid) {                                              // (the invalid half of a partly valid step: zeros, its halo was not loaded)
+                for (int i = 0; i < BM / 32; ++i) {
+                    const int px = dp + 32 * i;
+                    const int py = px / DP_TW, pxx = px - py * DP_TW;
+                    v4f a = b4;
+                    if (cvalid) {                                          // (the invalid half of a partly valid step: zeros, its halo was not loaded)
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky)
+                        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) a += halo[((py + ky) * DP_HW + pxx + kx) * 8 + dq] * wk[ky * 3 + kx];
-                    if (p.dw_act == (int)Act::RELU) {
+                            for (int kx = 0; kx < 3; ++kx) a += halo[((py + ky) * DP_HW + pxx + kx) * 8 + dq] * wk[ky * 3 + kx];
+                        if (p.dw_act == (int)Act::RELU) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : 0.f;
+                            for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : 0.f;
+                        }
                     }
+                    At[px * 8 + (dq ^ ((px >> 1) & 7))] = a;
                 }
-                At[px * 8 + (dq ^ ((px >> 1) & 7))] = a;
+            }
+        } else {
+            if (dq < 2 * ksteps) {
+                const float* cimg = img + cw;
+#pragma unroll
+                for (int i = 0; i < BM / 32; ++i) {
+                    const int px = dp + 32 * i;
+                    const int py = px / DP_TW, pxx = px - py * DP_TW;
+                    const int iy0 = (ty0 + py) * DS - 1, ix0 = (tx0 + pxx) * DS - 1;
+                    v4f a = b4;
+                    if (cvalid) {
+                        v4f x[9];
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 3; ++kx) {
+                                const int iy = iy0 + ky, ix = ix0 + kx;
+                                const bool in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                                x[ky * 3 + kx] = *reinterpret_cast<const v4f*>(in ? cimg + ((long)iy * p.W + ix) * C : p.zeros);
+                            }
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) a += x[k] * wk[k];
+                        if (p.dw_act == (int)Act::RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : 0.f;
+                        }
+                    }
+                    At[px * 8 + (dq ^ ((px >> 1) & 7))] = a;
+                }
             }
         }
         __syncthreads();                                                   // A tile complete
@@ -196,10 +230,12 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const in
 template <int BN, int WM, int WN>
 static void launch_dwpw_cfg(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.Wo + DP_TW - 1) / DP_TW, tiles_y = (a.Ho + DP_TH - 1) / DP_TH, tiles_n = (a.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN>), dim3((unsigned)(a.B * tiles_y * tiles_x * tiles_n)), dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
+    const dim3 grid((unsigned)(a.B * tiles_y * tiles_x * tiles_n));
+    if (a.dw_stride == 2) hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN, 2>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
+    else hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN, 1>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
 }
 
-// a.in = depthwise input [B,H,W,C] (stride 1: H x W = output grid), a.Cin = C, a.wt = packed pointwise weights
+// a.in = depthwise input [B,H,W,C] (a.dw_stride 1 | 2, pad 1; Ho x Wo = its output grid = the pointwise grid), a.Cin = C, a.wt = packed pointwise weights
 // [..][conv_kpad(C)], a.dw_w [9][C], a.dw_b [C]; activation of the pointwise part limited to NONE / RELU.
 void launch_dwpw(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;

@@ -202,7 +202,7 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 a.in = tensor_ptr(op.in);
                 a.wt = P + d.wt; a.bias = P + d.bias;
                 a.out1 = tensor_ptr(op.out);
-                a.dw_w = P + d.dww; a.dw_b = P + d.dwb; a.dw_act = (int)op.dw_act;
+                a.dw_w = P + d.dww; a.dw_b = P + d.dwb; a.dw_act = (int)op.dw_act; a.dw_stride = op.dw_stride;
                 a.B = batch; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
                 a.ks = 1; a.stride = 1; a.pad = 0; a.Kpad = d.Kpad; a.act = (int)op.act;
                 a.t_flops = 2.0 * op.macs * batch; a.t_bytes = op.bytes * batch;

@@ -57,6 +57,7 @@ struct ConvArgs {
     const float* dw_w;      // fused depthwise 3x3 front end (launch_dwpw): weights [9][Cin], bias [Cin], activation
     const float* dw_b;
     int dw_act;
+    int dw_stride;          // 1 | 2
     int n_outs;             // > 0: merged sibling convs — channels [oc0[g], oc0[g+1]) go to outs[g] with act oact[g]
     float* outs[3];
     int oc0[4];

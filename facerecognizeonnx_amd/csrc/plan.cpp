@@ -604,7 +604,7 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
         P.ops.swap(kept);
     }
 
-    // ---------------------------------------------------------------- 7c. depthwise 3x3 (stride 1) -> pointwise 1x1 fusion
+    // ---------------------------------------------------------------- 7c. depthwise 3x3 (stride 1 | 2) -> pointwise 1x1 fusion
     // (large maps only: the fused kernel works on 8x16 spatial tiles, small maps would be mostly padding)
     {
         auto uses = [&](int t) {
@@ -616,7 +616,7 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
         std::vector<bool> gone(P.ops.size(), false);
         for (size_t i = 0; i < P.ops.size(); ++i) {
             POp& d = P.ops[i];
-            if (d.kind != OpKind::DWCONV || d.stride != 1 || d.Ho * d.Wo < 1600 || uses(d.out) != 1) continue;
+            if (d.kind != OpKind::DWCONV || (d.stride != 1 && d.stride != 2) || d.Ho * d.Wo < (d.stride == 1 ? 1600 : 6400) || uses(d.out) != 1) continue;
             for (size_t j = i + 1; j < P.ops.size(); ++j) {
                 POp& c = P.ops[j];
                 if (c.in != d.out) continue;
@@ -628,7 +628,8 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
                 f.kind = OpKind::DWPW;
                 f.name = d.name + "+" + c.name;
                 f.in = d.in;
-                f.dw_weight = d.weight; f.dw_bias = d.bias; f.dw_act = d.act;
+                f.dw_weight = d.weight; f.dw_bias = d.bias; f.dw_act = d.act; f.dw_stride = d.stride;
+                f.H = d.H; f.W = d.W;
                 f.macs = d.macs + c.macs;
                 P.ops[j] = std::move(f);
                 gone[i] = true;
@@ -721,6 +722,7 @@ std::string Plan::describe() const {
         const POp& o = ops[i];
         os << i << " " << kinds[(int)o.kind] << " k" << o.ks << "s" << o.stride << " " << o.H << "x" << o.W << "x" << o.Cin
            << " -> " << o.Ho << "x" << o.Wo << "x" << o.Cout << acts[(int)o.act];
+        if (o.kind == OpKind::DWPW && o.dw_stride != 1) os << " (depthwise s" << o.dw_stride << ")";
         if (!o.outs.empty()) os << " [merged x" << o.outs.size() << "]";
         if (o.res >= 0) os << (o.res_mode == ResMode::UP2X ? " +res(up2x)" : " +res");
         if (o.out2 >= 0) os << (o.out >= 0 ? " +bn2nd" : " bn2nd-only");

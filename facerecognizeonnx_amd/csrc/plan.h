@@ -44,9 +44,11 @@ struct POp {
     // SCRFD cls/reg/kps branches): one GEMM with Cout = sum, channel range [out_c0[g], out_c0[g+1]) goes
     // to tensor outs[g] with activation out_act[g].  Empty = ordinary single-output conv.
     std::vector<int> outs, out_c0, out_act;
-    // DWPW: a stride-1 depthwise 3x3 (dw_weight [9][Cin], dw_bias, dw_act) feeding this op's 1x1 convolution
+    // DWPW: a depthwise 3x3 of stride dw_stride (dw_weight [9][Cin], dw_bias, dw_act) feeding this op's 1x1
+    // convolution; H x W = the depthwise INPUT, Ho x Wo = its output = the pointwise grid
     std::vector<float> dw_weight, dw_bias;
     Act dw_act = Act::NONE;
+    int dw_stride = 1;
     double macs = 0;                  // multiply-accumulates per image
     double bytes = 0;                 // algorithmic activation bytes per image (in + res + outs)
 };

@@ -77,18 +77,22 @@ def test_conv_layer_matches_oracle(B, H, W, Cin, Cout, k, stride, cfg):
 
 
 DWPW_CASES = [
-    # H,  W,  C, Cout     (H*W >= 1600 so that the planner fuses the pair; ragged tiles, channel counts off the 8/32 grid)
-    (40, 40, 16, 16),
-    (41, 53, 20, 72),
-    (48, 40, 40, 40),
-    (44, 60, 72, 96),
-    (40, 44, 36, 100),
-    (56, 40, 100, 24),
+    # H,  W,  C, Cout, depthwise stride   (maps large enough for the planner to fuse the pair; ragged tiles, channel
+    #                                      counts off the 8 / 32 grid)
+    (40, 40, 16, 16, 1),
+    (41, 53, 20, 72, 1),
+    (48, 40, 40, 40, 1),
+    (44, 60, 72, 96, 1),
+    (40, 44, 36, 100, 1),
+    (56, 40, 100, 24, 1),
+    (160, 160, 16, 40, 2),
+    (163, 175, 40, 72, 2),
+    (161, 166, 20, 100, 2),
 ]
 
 
-@pytest.mark.parametrize("H,W,Cc,Cout", DWPW_CASES)
-def test_depthwise_pointwise_block_matches_oracle(tmp_path, H, W, Cc, Cout):
+@pytest.mark.parametrize("H,W,Cc,Cout,ds", DWPW_CASES)
+def test_depthwise_pointwise_block_matches_oracle(tmp_path, H, W, Cc, Cout, ds):
     """The fused depthwise 3x3 -> pointwise 1x1 kernel (dwpw_mfma.hip) on a three-conv graph, vs the oracle."""
     from facerecognizeonnx_amd.synth.onnx_writer import OnnxBuilder
     rng = np.random.default_rng(H * 100 + Cc)
@@ -98,13 +102,13 @@ def test_depthwise_pointwise_block_matches_oracle(tmp_path, H, W, Cc, Cout):
         y = b.node("Conv", [x, b.init(b.uid("w"), w.astype(np.float32)), b.init(b.uid("b"), bias.astype(np.float32))], **kw)
         return b.node("Relu", [y]) if relu else y
     y = conv(x, rng.standard_normal((Cc, 3, 3, 3)) / 5, rng.standard_normal(Cc) / 10, kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[1, 1])
-    y = conv(y, rng.standard_normal((Cc, 1, 3, 3)) / 3, rng.standard_normal(Cc) / 10, kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[1, 1], group=Cc)
+    y = conv(y, rng.standard_normal((Cc, 1, 3, 3)) / 3, rng.standard_normal(Cc) / 10, kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[ds, ds], group=Cc)
     y = conv(y, rng.standard_normal((Cout, Cc, 1, 1)) / np.sqrt(Cc), rng.standard_normal(Cout) / 10, kernel_shape=[1, 1], strides=[1, 1])
     y = b.node("Transpose", [y], perm=[0, 2, 3, 1])
     b.node("Reshape", [y, b.init("shape", np.array([-1, Cout], np.int64))], outputs=["out"])
     b.add_output("out", ["A", Cout])
     path = b.save(str(tmp_path / "dwpw.onnx"))
-    assert "DW+PW" in fa.plan_describe(path, H, W)
+    assert "DW+PW" in fa.plan_describe(path, H, W) and ("(depthwise s2)" in fa.plan_describe(path, H, W)) == (ds == 2)
     det = fa.FaceDetector(); odet = oracle.OracleDetector()
     assert det.loadModel(path) and odet.loadModel(path)
     n = 2
