@@ -1,13 +1,14 @@
-// dwpw_mfma.hip — depthwise 3x3 stride-1 (+bias +ReLU) fused with the pointwise 1x1 convolution that
+// dwpw_mfma.hip — depthwise 3x3 of stride 1 or 2 (+bias +ReLU) fused with the pointwise 1x1 convolution that
 // consumes it: the MobileNet "conv_dw" block of SCRFD (ONNX Conv(group=C) -> Relu -> Conv 1x1 -> Relu,
 // executed by ORT inside session_->Run, reference src/face_detector.cpp:179-183).
 //
 // Run separately, these HBM-bound blocks write the depthwise result and read it straight back —
 // as much traffic as the block's real input and output together.  Here one workgroup owns a SPATIAL
 // tile of 8 x 16 output pixels and walks the channels in chunks of 32:
-//   1. the (8+2) x (16+2) input halo of the chunk goes global -> LDS by LDS-DMA (each element once,
-//      coalesced 128-byte pixel rows; out-of-image pixels and channels >= C come from the zero line),
-//      together with the pointwise weight chunk [BN][32];
+//   1. stride 1: the (8+2) x (16+2) input halo of the chunk goes global -> LDS by LDS-DMA (each element once,
+//      coalesced 128-byte pixel rows; out-of-image pixels come from the zero line, 16-byte channel columns
+//      >= C are not loaded at all), together with the pointwise weight chunk [BN][32];
+//      stride 2: no halo — vertical strips of outputs gather their taps from global memory (see DIRECT);
 //   2. the depthwise 3x3 (+bias +activation) is evaluated from LDS on the vector ALU, 4 channels per
 //      lane, and written to LDS as the GEMM's A tile [128 pixels][32 k] (XOR-swizzled like conv_mfma.hip);
 //   3. the pointwise product accumulates on v_mfma_f32_32x32x2_f32 exactly as in conv_igemm_kernel.
@@ -34,14 +35,22 @@ __device__ __forceinline__ void dwpw_dma16(const float* src, v4f* dst) {
 constexpr int DP_TH = 8, DP_TW = 16, DP_BM = DP_TH * DP_TW;            // 128 output pixels per tile
 constexpr int DP_HW = DP_TW + 2, DP_HALO = (DP_TH + 2) * DP_HW;         // 10 x 18 = 180 halo pixels
 
-// DS = stride of the depthwise part.  DS == 2 keeps no halo in LDS (a 17 x 33 halo would not fit beside the GEMM
-// tiles): every thread gathers the 9 taps of its outputs straight from global memory — each input pixel is
-// wanted by only 2.25 outputs on average and those re-reads hit L1 / L2.
-template <int BN, int WM, int WN, int DS>
-__global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_n) {
+// DS = stride of the depthwise part (1 | 2).
+// DIRECT = no halo in LDS: a thread owns 4 channels of a vertical strip of SR output pixels and gathers the
+// ((SR-1)*DS+3) x 3 input float4s of the strip straight from global memory into registers (re-reads between
+// neighbouring strips hit L1 / L2).  The register file is a far larger landing area than LDS (more bytes in
+// flight per CU) and the halo barrier disappears; it is the only form for DS == 2, whose 17 x 33 halo would not fit.
+// HC = 16-byte channel columns per pixel handled at a time: 8 (a 32-channel chunk), or 4 for layers with C <= 16 —
+// half the halo LDS, so more workgroups per CU, and no idle depthwise lanes.
+template <int BN, int WM, int WN, int DS, int HC, bool DIRECT>
+__global__ __launch_bounds__(256, DIRECT ? (BN * DS <= 64 ? 3 : 2) : HC == 4 ? 4 : 2) void dwpw_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_n) {
+    static_assert(DS == 1 || DIRECT, "stride 2 needs the direct form");
     constexpr int BM = DP_BM;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int HALO_SLOTS = DS == 1 ? (DP_HALO * 8 + 255) / 256 * 256 : 0;   // float4 slots, whole DMA passes
+    constexpr int HALO_SLOTS = !DIRECT ? (DP_HALO * HC + 255) / 256 * 256 : 0;  // float4 slots, whole DMA passes
+    constexpr int PPP = 256 / HC;                                          // pixels per depthwise pass
+    constexpr int SR = BM / PPP;                                           // DIRECT: output rows per thread strip
+    constexpr int NR = (SR - 1) * DS + 3;                                  //         input rows a strip touches
     __shared__ v4f lds[HALO_SLOTS + BM * 8 + BN * 8];
     v4f* const halo = lds;
     v4f* const At = lds + HALO_SLOTS;
@@ -61,19 +70,19 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const in
     const float* img = p.in + (size_t)n * p.H * p.W * C;                  // H x W = depthwise input, Ho x Wo = output grid
 
     // ---- halo loader: slot s = 256*j + tid covers halo pixel s>>3, 16-byte column s&7
-    constexpr int HP = DS == 1 ? HALO_SLOTS / 256 : 1;
+    constexpr int HP = !DIRECT ? HALO_SLOTS / 256 : 1;
     long h_off[HP];                                                        // float offset of (pixel, column 0) or -1
 #pragma unroll
-    for (int j = 0; j < (DS == 1 ? HP : 0); ++j) {
-        const int s = j * 256 + tid, hp = s >> 3;
+    for (int j = 0; j < (!DIRECT ? HP : 0); ++j) {
+        const int s = j * 256 + tid, hp = s / HC;
         h_off[j] = -1;
         if (hp < DP_HALO) {
             const int hy = hp / DP_HW, hx = hp - hy * DP_HW;
             const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
-            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) h_off[j] = ((long)iy * p.W + ix) * C + (s & 7) * 4;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) h_off[j] = ((long)iy * p.W + ix) * C + (s % HC) * 4;
         }
     }
-    const int hq = tid & 7;                                                // same for every pass (256 % 8 == 0)
+    const int hq = tid % HC;                                               // same for every pass (256 % HC == 0)
     // ---- pointwise weight loader (as conv_mfma.hip: LDS-DMA, swizzle on the source column)
     const int lrow = tid >> 3;
     const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);
@@ -83,8 +92,8 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const in
 #pragma unroll
     for (int i = 0; i < BL; ++i) w_off[i] = (unsigned)(((lrow + i * 32) * p.Kpad + lqs * 4) * 4);
 
-    // ---- depthwise producer: thread -> 16-byte column dq of pixels dp + 32*i
-    const int dq = tid & 7, dp = tid >> 3;
+    // ---- depthwise producer: thread -> 16-byte column dq of pixels dp + PPP*i
+    const int dq = tid % HC, dp = tid / HC;
     const int fr = lane & 31, fh2 = lane >> 5, fsw = (fr >> 1) & 7;
 
     v16f acc[TM][TN];
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const in
         const bool hvalid = c0 + hq * 4 < C;                               // 16-byte columns past C are never read: no DMA for them
         const int ksteps = min(4, (C - c0 + 7) >> 3);                      // 8-deep MFMA steps that hold real channels
         __syncthreads();                                                   // previous chunk: halo + fragments fully consumed
-        if (DS == 1 && hvalid) {
+        if (!DIRECT && hvalid) {
 #pragma unroll
             for (int j = 0; j < HP; ++j) {
                 const float* src = h_off[j] >= 0 ? img + h_off[j] + c0 : p.zeros;
@@ -117,19 +126,19 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const in
 #pragma unroll
         for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const v4f*>(cvalid ? p.dw_w + (size_t)k * C + cw : p.zeros);
         b4 = *reinterpret_cast<const v4f*>(cvalid ? p.dw_b + cw : p.zeros);
-        if (DS == 1) {
+        if (!DIRECT) {
             __syncthreads();                                               // halo + weights landed (barrier drains vmcnt)
             if (dq < 2 * ksteps) {
 #pragma unroll
-                for (int i = 0; i < BM / 32; ++i) {
-                    const int px = dp + 32 * i;
+                for (int i = 0; i < BM / PPP; ++i) {
+                    const int px = dp + PPP * i;
                     const int py = px / DP_TW, pxx = px - py * DP_TW;
                     v4f a = b4;
                     if (cvalid) {                                          // (the invalid half of a partly valid step: zeros, its halo was not loaded)
 #pragma unroll
                         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                            for (int kx = 0; kx < 3; ++kx) a += halo[((py + ky) * DP_HW + pxx + kx) * 8 + dq] * wk[ky * 3 + kx];
+                            for (int kx = 0; kx < 3; ++kx) a += halo[((py + ky) * DP_HW + pxx + kx) * HC + dq] * wk[ky * 3 + kx];
                         if (p.dw_act == (int)Act::RELU) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : 0.f;
@@ -140,31 +149,40 @@ __global__ __launch_bounds__(256, 2) void dwpw_kernel(const ConvArgs p, const in
             }
         } else {
             if (dq < 2 * ksteps) {
+                const int sx = dp % DP_TW, sy = dp / DP_TW;                 // strip: column sx, output rows sy*SR .. sy*SR+SR-1
+                const int iy0 = (ty0 + sy * SR) * DS - 1, ix0 = (tx0 + sx) * DS - 1;
                 const float* cimg = img + cw;
+                v4f a[SR];
 #pragma unroll
-                for (int i = 0; i < BM / 32; ++i) {
-                    const int px = dp + 32 * i;
-                    const int py = px / DP_TW, pxx = px - py * DP_TW;
-                    const int iy0 = (ty0 + py) * DS - 1, ix0 = (tx0 + pxx) * DS - 1;
-                    v4f a = b4;
-                    if (cvalid) {
-                        v4f x[9];
+                for (int o = 0; o < SR; ++o) a[o] = b4;
+                if (cvalid) {
 #pragma unroll
-                        for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int ix = ix0 + kx;
+                        const bool xin = (unsigned)ix < (unsigned)p.W;
+                        v4f x[NR];
 #pragma unroll
-                            for (int kx = 0; kx < 3; ++kx) {
-                                const int iy = iy0 + ky, ix = ix0 + kx;
-                                const bool in = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                                x[ky * 3 + kx] = *reinterpret_cast<const v4f*>(in ? cimg + ((long)iy * p.W + ix) * C : p.zeros);
-                            }
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) a += x[k] * wk[k];
-                        if (p.dw_act == (int)Act::RELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) a[e] = a[e] > 0.f ? a[e] : 0.f;
+                        for (int r = 0; r < NR; ++r) {
+                            const int iy = iy0 + r;
+                            const bool in = xin && (unsigned)iy < (unsigned)p.H;
+                            x[r] = *reinterpret_cast<const v4f*>(in ? cimg + ((long)iy * p.W + ix) * C : p.zeros);
                         }
+#pragma unroll
+                        for (int o = 0; o < SR; ++o)
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky) a[o] += x[o * DS + ky] * wk[ky * 3 + kx];
                     }
-                    At[px * 8 + (dq ^ ((px >> 1) & 7))] = a;
+                    if (p.dw_act == (int)Act::RELU) {
+#pragma unroll
+                        for (int o = 0; o < SR; ++o)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) a[o][e] = a[o][e] > 0.f ? a[o][e] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < SR; ++o) {
+                    const int px = (sy * SR + o) * DP_TW + sx;
+                    At[px * 8 + (dq ^ ((px >> 1) & 7))] = a[o];
                 }
             }
         }
@@ -231,8 +249,11 @@ template <int BN, int WM, int WN>
 static void launch_dwpw_cfg(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.Wo + DP_TW - 1) / DP_TW, tiles_y = (a.Ho + DP_TH - 1) / DP_TH, tiles_n = (a.Cout + BN - 1) / BN;
     const dim3 grid((unsigned)(a.B * tiles_y * tiles_x * tiles_n));
-    if (a.dw_stride == 2) hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN, 2>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
-    else hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN, 1>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
+    // (the direct form was measured for stride 1 too: 15-20 % slower than the LDS halo on every SCRFD layer —
+    //  L1 traffic of the 4.5-6x re-reads costs more than the extra loads in flight gain)
+    if (a.dw_stride == 2) hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN, 2, 8, true>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
+    else if (a.Cin <= 16 && BN <= 64) hipLaunchKernelGGL((dwpw_kernel<(BN <= 64 ? BN : 64), (BN <= 64 ? WM : 2), (BN <= 64 ? WN : 2), 1, 4, false>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
+    else hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN, 1, 8, false>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
 }
 
 // a.in = depthwise input [B,H,W,C] (a.dw_stride 1 | 2, pad 1; Ho x Wo = its output grid = the pointwise grid), a.Cin = C, a.wt = packed pointwise weights
