@@ -1,0 +1,12 @@
+#!/bin/bash
+# Runs the other BASELINE.json configurations on the GPU box; one JSON line each into gpurun_out/secondary/.
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/secondary; mkdir -p $O
+run() { name=$1; shift; python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline "$@" > $O/$name.json 2> $O/$name.err || echo "FAILED $name"; }
+run headline
+run c2_embed --workload embed
+run c3_detect --workload detect
+run f4 --faces-per-frame 4
+run c4_gallery --gallery 1000000 --frames 64
+run from_host --from-host
+run overlap --overlap
+ls $O

@@ -1,0 +1,26 @@
+"""Formats gpurun_out/secondary/*.json (scripts/secondary_configs.sh) into profiles/<tag>_secondary_configs.md"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rows = [("headline", "headline: 128 frames 640x640, detect+align+embed, F=1", "(default)"),
+        ("c2_embed", "C2: ArcFace w600k_r50, 256 pre-aligned crops", "`--workload embed`"),
+        ("c3_detect", "C3: SCRFD det_500m + decode + NMS, 128 frames", "`--workload detect`"),
+        ("f4", "headline with 4 faces per frame", "`--faces-per-frame 4`"),
+        ("c4_gallery", "C4: 64 frames end-to-end + top-16 of a 1 M x 512 gallery", "`--gallery 1000000 --frames 64`"),
+        ("from_host", "PCIe-inclusive headline (pinned host frames, double-buffered H2D)", "`--from-host`"),
+        ("overlap", "headline, streaming form: detector of batch k+1 on its own stream beside the recogniser of batch k", "`--overlap`")]
+out = [f"# Round {tag} — other BASELINE.json configurations (same build as profiles/{tag}_summary.md)", "",
+       "`python bench.py --steps 10 --warmup 3 --no-cpu-baseline <args>` on one MI355X, HBM-resident inputs unless stated, fp32.", "",
+       "| config | args | value | ms / step | dominant kernel (achieved, frac of its roofline) | all conv launches |", "|---|---|---|---|---|---|"]
+for name, desc, args in rows:
+    p = os.path.join(ROOT, "gpurun_out", "secondary", name + ".json")
+    try:
+        d = json.loads(open(p).read().strip().splitlines()[-1])
+    except Exception as e:
+        out.append(f"| {desc} | {args} | (no result: {e}) | | | |"); continue
+    r = d.get("roofline") or {}
+    dom = f"{r.get('kernel', '—')} {r.get('achieved', 0):.1f} {r.get('unit', '')}, {r.get('frac', 0):.3f}" if r else "—"
+    allc = r.get("all_conv_igemm", {})
+    out.append(f"| {desc} | {args} | {d['value']:,.0f} {d['unit']} | {d['ms_per_step']:.2f} | {dom} | {allc.get('achieved', 0):.1f} TF |")
+open(os.path.join(ROOT, "profiles", f"{tag}_secondary_configs.md"), "w").write("\n".join(out) + "\n")
+print("\n".join(out))
