@@ -55,7 +55,7 @@ def parse():
                     "512-d rows (row-sharded over the ranks; per-rank top-k all-gathered and merged)")
     ap.add_argument("--topk", type=int, default=16)
     ap.add_argument("--overlap", action="store_true", help="e2e: streaming form (fh_pipeline_submit_dev) — the detector of batch k+1 runs "
-                    "on its own HIP stream beside the recogniser of batch k (+3.6 % measured).  Not the default because per-kernel "
+                    "on its own HIP stream beside the recogniser of batch k (+1.6 to 3.6 %% measured).  Not the default because per-kernel "
                     "durations then include time-sharing with the other network's kernels, which blurs the roofline attribution")
     ap.add_argument("--from-host", action="store_true", help="secondary measurement: frames start in pinned HOST memory and are "
                     "uploaded over PCIe, double-buffered on a side stream (the PCIe-inclusive rate; never the headline value)")

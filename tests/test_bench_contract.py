@@ -1,0 +1,36 @@
+"""bench.py's output contract, checked on the committed line of the last measured run (profiles/r01_bench_line.json)
+and on the argument parser (no GPU needed)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    with open(os.path.join(ROOT, "profiles", "r01_bench_line.json")) as f:
+        d = json.loads(f.read().strip().splitlines()[-1])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"].replace("x", "×") == base["metric"] or d["metric"] == base["metric"].replace("×", "x")
+    for k in ("value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    # value = faces the step produced / step time
+    faces = d["config"]["faces_per_step_rank0"] * d["n_gpus"]
+    assert abs(d["value"] - faces / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_bench_cli_accepts_the_driver_flags():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
