@@ -40,6 +40,12 @@ struct DecodeError {
 };
 [[noreturn]] void fail(const std::string& m) { throw DecodeError{m}; }
 
+// Header sanity: a corrupt file must not make the decoder allocate gigabytes (OpenCV: CV_IO_MAX_IMAGE_PIXELS = 2^30).
+constexpr long long kMaxPixels = 1LL << 28;
+void check_size(long long w, long long h, const char* fmt) {
+    if (w <= 0 || h <= 0 || w > (1 << 20) || h > (1 << 20) || w * h > kMaxPixels) fail(std::string(fmt) + ": unreasonable image size");
+}
+
 // =====================================================================================================
 // JPEG
 // =====================================================================================================
@@ -171,6 +177,7 @@ struct Jpeg {
         if (p[0] != 8) fail("JPEG: only 8-bit precision is supported");
         height = u16(p + 1); width = u16(p + 3); ncomp = p[5];
         if (width <= 0 || height <= 0) fail("JPEG: empty image");
+        check_size(width, height, "JPEG");
         if (ncomp != 1 && ncomp != 3) fail("JPEG: only 1- and 3-component images are supported");
         if (len < 6 + 3 * ncomp) fail("JPEG: short SOF");
         for (int i = 0; i < ncomp; ++i) {
@@ -683,6 +690,7 @@ Image decode_png(const uint8_t* d, size_t n) {
             if (len < 13) fail("PNG: bad IHDR");
             W = (int)be32(body); H = (int)be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12];
             if (W <= 0 || H <= 0 || body[10] != 0 || body[11] != 0 || interlace > 1) fail("PNG: unsupported header");
+            check_size(W, H, "PNG");
             have_hdr = true;
         } else if (!memcmp(type, "PLTE", 4)) {
             plte.assign(body, body + len);
@@ -785,6 +793,7 @@ Image decode_bmp(const uint8_t* d, size_t n) {
     const int W = le32(18), Hs = le32(22), bpp = le16(28), comp = le32(30);
     if (le16(26) != 1 || (bpp != 24 && bpp != 32) || (comp != 0 && !(comp == 3 && bpp == 32)) || W <= 0 || Hs == 0) fail("BMP: only uncompressed 24/32-bit files are supported");
     const int H = abs(Hs);
+    check_size(W, H, "BMP");
     const size_t stride = ((size_t)W * (bpp / 8) + 3) & ~(size_t)3;
     if (data_off + stride * H > n) fail("BMP: truncated pixel data");
     Image img;
@@ -813,6 +822,7 @@ Image decode_pnm(const uint8_t* d, size_t n) {
     const int ch = d[1] == '6' ? 3 : 1;
     const int W = next_int(), H = next_int(), maxv = next_int();
     if (W <= 0 || H <= 0 || maxv <= 0 || maxv > 255) fail("PNM: only 8-bit binary files are supported");
+    check_size(W, H, "PNM");
     ++pos;                                                        // the single whitespace byte after maxval
     if (pos + (size_t)W * H * ch > n) fail("PNM: truncated pixel data");
     Image img;

@@ -67,6 +67,10 @@ def test_corrupt_and_unsupported_inputs_fail_cleanly():
     with open(os.path.join(IMAGES, "p_rgb.png"), "rb") as f:
         png = f.read()
     assert decode(png[:60]) is None and "PNG" in _lib.last_error()
+    huge = bytearray(data)                                                  # a header that claims 65535 x 65535 pixels
+    sof = data.index(b"\xff\xc0")
+    huge[sof + 5: sof + 9] = b"\xff\xff\xff\xff"
+    assert decode(bytes(huge)) is None and "unreasonable" in _lib.last_error()
     rng = np.random.default_rng(0)
     for _ in range(200):                                                   # bit flips must never crash the decoder
         b = bytearray(data)
