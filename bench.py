@@ -34,7 +34,9 @@ sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 CFG_NAMES = ["conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<256,64,4,1>", "conv_igemm_kernel<128,32,4,1>",
-             "conv_igemm_kernel<64,64,2,2>", "dwpw_kernel + dwconv3x3 kernels", "other graph ops (incl. stem_conv_u8)", "conv_fixup_kernel"]
+             "conv_igemm_kernel<64,64,2,2>", "dwpw_kernel + dwconv3x3 kernels", "other graph ops (incl. stem_conv_u8)", "conv_fixup_kernel",
+             "conv_igemm_kernel<128,32,4,1> as Winograd F(4x4,3x3) GEMM (36 groups)", "wino_input_kernel + wino_output_kernel"]
+NTAGS = len(CFG_NAMES)
 
 
 def parse():
@@ -275,8 +277,8 @@ def main():
     # Kernel-level roofline leg: the same steps again with the library's per-launch HIP events switched on.
     # It runs right AFTER the timed region (not inside it) because the ~250 event records per step cost
     # ~6 % of the step (22.8 vs 21.5 ms); `value` must not carry the instrumentation.
-    ms, fl, by = (C.c_double * 7)(), (C.c_double * 7)(), (C.c_double * 7)()
-    ln = (C.c_longlong * 7)()
+    ms, fl, by = (C.c_double * NTAGS)(), (C.c_double * NTAGS)(), (C.c_double * NTAGS)()
+    ln = (C.c_longlong * NTAGS)()
     isteps = 0
     instr_dt = 0.0
     if timing:
@@ -290,7 +292,7 @@ def main():
         instr_dt = time.perf_counter() - ti
         drain()
         L.fh_timing_enable(0)
-        fa._lib.check(L.fh_timing_collect(ms, fl, by, ln, 7), "fh_timing_collect")
+        fa._lib.check(L.fh_timing_collect(ms, fl, by, ln, NTAGS), "fh_timing_collect")
 
     total_units, max_dt = float(units), dt
     if dist is not None:
@@ -328,11 +330,15 @@ def main():
                                                                      if args.gallery and world > 1 else "no data-path collective")},
         }
         if timing:
-            conv = [(ms[i], fl[i], ln[i], i) for i in range(4) if ln[i] > 0]
+            conv = [(ms[i], fl[i], ln[i], i) for i in (0, 1, 2, 3, 7) if ln[i] > 0]
             if conv:
                 dom = max(conv)
                 tf = dom[1] / (dom[0] * 1e-3) / 1e12
-                allms, allfl = sum(c[0] for c in conv) + ms[6], sum(c[1] for c in conv)   # fix-up time counts against the convs
+                # fix-up and Winograd-transform time counts against the convs; FLOPs = what the matrix cores EXECUTE
+                allms, allfl = sum(c[0] for c in conv) + ms[6] + ms[8], sum(c[1] for c in conv)
+                # the same launches priced with the direct-form FLOPs of the layers they compute (Winograd GEMMs stand for 4x
+                # their own work; the timer carries that figure in the bytes slot of tag 7)
+                algfl = sum(fl[i] for i in (0, 1, 2, 3)) + by[7]
                 traffic = None
                 tpath = os.path.join(ROOT, "profiles", "traffic.json")     # written by scripts/summarize_profile.py from --pmc runs
                 if os.path.exists(tpath):
@@ -342,10 +348,13 @@ def main():
                                    "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                    "launches": int(dom[2]), "avg_launch_us": 1e3 * dom[0] / dom[2],
                                    "algorithmic_gflop_per_launch": dom[1] / dom[2] / 1e9,
+                                   "flops_counted": "executed by the matrix cores (a Winograd GEMM is booked with its own 36-group "
+                                                    "product, not with the 4x larger direct-form count of the layer)",
                                    "all_conv_igemm": {"achieved": allfl / (allms * 1e-3) / 1e12,
                                                       "frac": allfl / (allms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                                                      "ms_per_step": allms / isteps},
-                                   "per_kernel_ms_per_step": {CFG_NAMES[i]: ms[i] / isteps for i in range(7) if ln[i] > 0},
+                                                      "ms_per_step": allms / isteps,
+                                                      "direct_form_equivalent_tflops": algfl / (allms * 1e-3) / 1e12},
+                                   "per_kernel_ms_per_step": {CFG_NAMES[i]: ms[i] / isteps for i in range(NTAGS) if ln[i] > 0},
                                    "measured_on": f"{isteps} instrumented steps run right after the timed region (same inputs); "
                                                   f"instrumented step = {1e3 * instr_dt / isteps:.2f} ms"}
         if not args.no_cpu_baseline and world == 1:

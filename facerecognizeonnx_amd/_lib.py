@@ -87,12 +87,15 @@ PROTOTYPES = {
     "fh_imread": (_i, [C.c_char_p, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)]),
     "fh_image_decode": (_i, [_vp, C.c_size_t, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)]),
     "fh_image_free": (None, [_vp]),
+    "fh_det_set_winograd": (_i, [_vp, _i]),
+    "fh_rec_set_winograd": (_i, [_vp, _i]),
     "fh_det_set_cus": (_i, [_vp, _i]),
     "fh_rec_set_cus": (_i, [_vp, _i]),
     "fh_det_set_fused_stem": (_i, [_vp, _i]),
     "fh_rec_set_fused_stem": (_i, [_vp, _i]),
     "fh_resize_u8c3_dev": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "fh_conv_forward_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "fh_conv_winograd_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fh_conv_wt_rows": (_i, [_i]),
     "fh_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
     "fh_conv_kpad": (_i, [_i]),

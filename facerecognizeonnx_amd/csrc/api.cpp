@@ -324,7 +324,7 @@ int fh_gallery_topk_dev(fh_gallery* g, const float* q, int nq, int k, float* sco
 // ---------------------------------------------------------------------------------- timing / tuning
 int fh_timing_enable(int on) { fh::KernelTimer::get().enabled = on != 0; return FH_OK; }
 int fh_timing_collect(double* ms, double* flops, double* bytes, long long* launches, int n) {
-    if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need 7-entry arrays");
+    if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need 9-entry arrays");
     return guarded([&] { fh::KernelTimer::get().collect(ms, flops, bytes, launches); return fh::KernelTimer::kTags; });
 }
 int fh_timing_collect_ops(double* ms, double* flops, int* tag, int cap) {
@@ -336,6 +336,8 @@ int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k) {
     d->det.net().force_cfg = cfg; d->det.net().sk_enable = stream_k != 0;
     return FH_OK;
 }
+int fh_det_set_winograd(fh_det* d, int on) { if (!d) return arg_error("null handle"); d->det.net().winograd = on != 0; return FH_OK; }
+int fh_rec_set_winograd(fh_rec* r, int on) { if (!r) return arg_error("null handle"); r->rec.net().winograd = on != 0; return FH_OK; }
 int fh_det_set_cus(fh_det* d, int cus) { if (!d || cus < 0) return arg_error("bad argument"); d->det.net().cus = cus; return FH_OK; }
 int fh_rec_set_cus(fh_rec* r, int cus) { if (!r || cus < 0) return arg_error("bad argument"); r->rec.net().cus = cus; return FH_OK; }
 int fh_det_set_fused_stem(fh_det* d, int on) { if (!d) return arg_error("null handle"); d->det.net().fuse_stem = on != 0; return FH_OK; }
@@ -356,6 +358,41 @@ int fh_resize_u8c3_dev(const uint8_t* src, int sh, int sw, int sstep, uint8_t* d
     return guarded([&] {
         fh::launch_resize_u8c3(src, (long)sh * sstep, sh, sw, sstep, dst, (long)dh * dstep, dh, dw, dstep, 1, S(stream));
         FH_HIP(hipGetLastError());
+        return 0;
+    });
+}
+// Winograd form of one 3x3 stride-1 pad-1 convolution (+bias), for the parity tests: w_ohwi = host weights [cout][3*3][cin]
+int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi, const float* d_bias, float* d_out, int batch, int h, int w, int cin,
+                         int cout, void* stream) {
+    if (!d_in || !w_ohwi || !d_out || cin % 32 || cout % 4) return arg_error("fh_conv_winograd_dev: bad argument");
+    return guarded([&] {
+        const int rows = fh::conv_wt_rows(cout);
+        std::vector<float> u36((size_t)36 * rows * cin, 0.f), uf((size_t)cout * cin);
+        std::vector<double> uall((size_t)cout * cin * 36);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci) {
+                double g[9];
+                for (int t = 0; t < 9; ++t) g[t] = w_ohwi[((size_t)co * 9 + t) * cin + ci];
+                fh::wino_filter_transform(g, &uall[((size_t)co * cin + ci) * 36]);
+            }
+        for (int f = 0; f < 36; ++f) {
+            for (size_t e = 0; e < uf.size(); ++e) uf[e] = (float)uall[e * 36 + f];
+            fh::conv_pack_weights(uf.data(), cout, cin, 1, u36.data() + (size_t)f * rows * cin);
+        }
+        const size_t tiles = (size_t)batch * ((h + 3) / 4) * ((w + 3) / 4);
+        fh::DevBuf dU, dV, dM;
+        dU.ensure(u36.size() * sizeof(float));
+        dV.ensure(36 * tiles * cin * sizeof(float));
+        dM.ensure(36 * tiles * cout * sizeof(float));
+        FH_HIP(hipMemcpy(dU.p, u36.data(), u36.size() * sizeof(float), hipMemcpyHostToDevice));
+        static fh::DevBuf slabs;
+        if (!slabs.p) { slabs.ensure(fh::conv_slab_floats() * sizeof(float)); fh::conv_workspace_init(slabs.as<float>()); }
+        fh::ConvArgs a{};
+        a.in = d_in; a.bias = d_bias; a.out1 = d_out; a.slabs = slabs.as<float>(); a.sk_enable = 1;
+        a.B = batch; a.H = h; a.W = w; a.Ho = h; a.Wo = w; a.Cin = cin; a.Cout = cout; a.ks = 3; a.stride = 1; a.pad = 1;
+        a.act = (int)fh::Act::NONE; a.res_mode = (int)fh::ResMode::NONE;
+        fh::launch_conv_winograd(a, dU.as<float>(), dV.as<float>(), dM.as<float>(), 2, S(stream));
+        FH_HIP(hipStreamSynchronize(S(stream)));                 // the workspaces die with this scope
         return 0;
     });
 }

@@ -83,13 +83,13 @@ struct Tile {
 // C/D map of the 32x32 MFMA: column (= pixel here) = lane & 31, row (= channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0,
-                                              int wm, int wn, int lane, int only_i = -1, int only_j = -1) {
+                                              int wm, int wn, int lane, int only_i = -1, int only_j = -1, long out_off = 0) {
     using TL = Tile<BM, BN, WM, WN>;
     const int fr = lane & 31, fh2 = lane >> 5;
     const int HoWo = p.Ho * p.Wo;
     const int M = p.B * HoWo;
     const float* __restrict__ res = p.res;
-    float* __restrict__ out1 = p.out1;
+    float* __restrict__ out1 = p.out1 ? p.out1 + out_off : nullptr;   // (out_off: grouped GEMM, see ConvArgs::tpg)
     float* __restrict__ out2 = p.out2;
     const bool vec = (p.Cout & 3) == 0;
     if (p.n_outs > 0) {                                  // merged sibling convs: per-channel-range destination
@@ -170,7 +170,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
     }
 }
 
-template <int BM, int BN, int WM, int WN, int OCC, bool FAST>
+// GRP: grouped form (several independent GEMMs in one launch) — a separate instantiation, so that the ungrouped convolutions keep
+// their register allocation (with the group decode compiled in, the 128x128 / 256x64 kernels spilled 328 bytes per lane).
+template <int BM, int BN, int WM, int WN, int OCC, bool FAST, bool GRP>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const ConvArgs p, const int tiles_n, const int chunks) {
     using TL = Tile<BM, BN, WM, WN>;
     constexpr int TM = TL::TM, TN = TL::TN, RP = TL::RP, AL = TL::AL, BL = TL::BL;
@@ -223,7 +225,17 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
             part = helper_id - (r * Kh) / p.sk_q;           // position among the helpers that touch this tile
             hu += len;
         }
-        const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+        // grouped form (Winograd's 36 independent GEMMs): tile -> (group, tile inside the group), per-group operand bases
+        int tl = tile;
+        const float* g_in = p.in;
+        const float* g_wt = p.wt;
+        long g_out = 0;
+        if (GRP && p.tpg > 0) {
+            const int g = tile / p.tpg;
+            tl = tile - g * p.tpg;
+            g_in += (size_t)g * p.in_gs; g_wt += (size_t)g * p.wt_gs; g_out = (long)g * p.out_gs;
+        }
+        const int tile_n = tl % tiles_n, tile_m = tl / tiles_n;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
 
         // ---- loader bookkeeping.  LDS-DMA (global_load_lds_dwordx4) writes lane l of a wave at
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                 const int n = m / HoWo, rem = m - n * HoWo;
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-                a_ptr[i] = p.in + (long)(((n * p.H + iy0) * p.W + ix0) * p.Cin) + lqs * 4;
+                a_ptr[i] = g_in + (long)(((n * p.H + iy0) * p.W + ix0) * p.Cin) + lqs * 4;
                 unsigned mk = 0;
                 if (p.ks == 3) {
 #pragma unroll
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
         }
         // weights: wave-uniform base that advances 128 B per chunk + a constant 32-bit lane offset
         // (lets the loads use the scalar-base addressing form: no per-chunk vector pointer math)
-        const char* w_base = reinterpret_cast<const char*>(p.wt) + ((size_t)n0 * p.Kpad + (size_t)c_begin * 32) * 4;
+        const char* w_base = reinterpret_cast<const char*>(g_wt) + ((size_t)n0 * p.Kpad + (size_t)c_begin * 32) * 4;
         unsigned w_off[BL];
 #pragma unroll
         for (int i = 0; i < BL; ++i) w_off[i] = (unsigned)(((lrow + i * RP) * p.Kpad + lqs * 4) * 4);
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                         }
             }
         }
-        conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+        conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane, -1, -1, g_out);
     } while (role == HELPER && hu < hu_end);
 }
 
@@ -459,8 +471,11 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             if (i == si && j == sj) acc[i][j] = sum;
-    const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
-    conv_epilogue<BM, BN, WM, WN>(p, acc, tile_m * BM, tile_n * BN, wm, wn, lane, si, sj);
+    int tl = tile;
+    long g_out = 0;
+    if (p.tpg > 0) { const int g = tile / p.tpg; tl = tile - g * p.tpg; g_out = (long)g * p.out_gs; }
+    const int tile_n = tl % tiles_n, tile_m = tl / tiles_n;
+    conv_epilogue<BM, BN, WM, WN>(p, acc, tile_m * BM, tile_n * BN, wm, wn, lane, si, sj, g_out);
 }
 
 int conv_wt_rows(int Cout) { return (Cout + 127) / 128 * 128; }
@@ -533,7 +548,9 @@ template <int BM, int BN, int WM, int WN, int OCC>
 static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t s) {
     const long M = (long)a.B * a.Ho * a.Wo;
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (a.Cout + BN - 1) / BN;
-    const int T = tiles_m * tiles_n;
+    const int groups = a.groups > 1 ? a.groups : 1;
+    a.tpg = groups > 1 ? tiles_m * tiles_n : 0;
+    const int T = tiles_m * tiles_n * groups;
     const int chunks = a.Kpad / 32;
     const int S = (a.cus > 0 ? a.cus : num_cus()) * resident_per_cu;
     a.zeros = conv_zero_line();
@@ -575,11 +592,14 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
     const dim3 grid((unsigned)(full + helpers + owners));
-    if ((a.Cin & 31) == 0)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+    if (groups > 1) {
+        if ((a.Cin & 31) != 0) { a.tpg = 0; }                  // (callers only group 32-aligned depths; never reached)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true, true>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+    } else if ((a.Cin & 31) == 0)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true, false>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, false>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
-    timer.end(s, cfg_tag, a.t_flops, a.t_bytes);
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, false, false>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+    timer.end(s, a.groups > 1 ? 7 : cfg_tag, a.t_flops, a.t_bytes);   // (grouped = Winograd GEMM: its own tag)
     if (fixup) {
         timer.begin(s);
         hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, WM, WN>), dim3((unsigned)(R * (BM / WM / 32) * (BN / WN / 32))), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);

@@ -1,6 +1,7 @@
 // engine.cpp — weight upload, arena management and the launch sequences of the face path.
 #include "engine.h"
 
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -66,6 +67,10 @@ int KernelTimer::collect_ops(double* ms, double* flops, int* tag, int cap) {
 
 // ------------------------------------------------------------------------------------------ Net
 
+// Winograd pays from 128 input channels on (IResNet-50, B = 128: 14.13 ms direct, 11.2 ms with >= 256, 10.5 ms with >= 128,
+// 10.6 ms with >= 64: below 128 the two transform passes cost what the matrix cores save)
+static constexpr int kWinoMinCin = 128;
+
 Net::Net(const std::string& onnx_path, int default_h, int default_w) {
     OnnxModel m = load_onnx(onnx_path);
     // reference src/face_detector.cpp:39-57: adopt the model's static H/W when > 0, else keep defaults
@@ -99,6 +104,26 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
             std::vector<float> packed((size_t)rows * d.Kpad, 0.f);
             conv_pack_weights(op.weight.data(), op.Cout, op.Cin, op.ks, packed.data());
             d.wt = push(packed.data(), packed.size());
+            // Winograd F(4x4,3x3) image of the same filter: U[f] = G g G^T in fp64, one packed [rows][Cin] matrix per frequency
+            if (op.kind == OpKind::CONV && op.ks == 3 && op.stride == 1 && op.pad == 1 && op.Cin >= kWinoMinCin && op.Cin % 32 == 0 &&
+                op.Cout % 4 == 0 && op.outs.empty() && op.res_mode != ResMode::UP2X) {
+                std::vector<float> u36((size_t)36 * rows * op.Cin, 0.f), uf((size_t)op.Cout * op.Cin);
+                std::vector<double> uall((size_t)op.Cout * op.Cin * 36);
+                for (int co = 0; co < op.Cout; ++co)
+                    for (int ci = 0; ci < op.Cin; ++ci) {
+                        double g[9];
+                        for (int t = 0; t < 9; ++t) g[t] = op.weight[((size_t)co * 9 + t) * op.Cin + ci];
+                        wino_filter_transform(g, &uall[((size_t)co * op.Cin + ci) * 36]);
+                    }
+                for (int f = 0; f < 36; ++f) {
+                    for (size_t e = 0; e < uf.size(); ++e) uf[e] = (float)uall[e * 36 + f];
+                    conv_pack_weights(uf.data(), op.Cout, op.Cin, 1, u36.data() + (size_t)f * rows * op.Cin);
+                }
+                d.w36 = push(u36.data(), u36.size());
+                d.wino = true;
+                const size_t tiles = (size_t)((op.H + 3) / 4) * ((op.W + 3) / 4);
+                wino_elems_ = std::max(wino_elems_, 36 * tiles * (size_t)std::max(op.Cin, op.Cout));
+            }
         } else if (op.kind == OpKind::DWCONV) {
             d.wt = push(op.weight.data(), op.weight.size());
         }
@@ -131,6 +156,10 @@ void Net::reserve(int max_batch) {
     if (partial_.bytes < conv_slab_floats() * sizeof(float)) {
         partial_.ensure(conv_slab_floats() * sizeof(float));
         conv_workspace_init(partial_.as<float>());
+    }
+    if (wino_elems_) {
+        wino_v_.ensure(wino_elems_ * (size_t)cap_ * sizeof(float));
+        wino_m_.ensure(wino_elems_ * (size_t)cap_ * sizeof(float));
     }
     // the 4th input lane and alignment gaps must never hold NaNs
     FH_HIP(hipMemset(arena_.p, 0, arena_.bytes));
@@ -193,6 +222,14 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 int cfg = force_cfg >= 0 ? force_cfg : conv_pick_cfg(M, op.Cout);
                 if (force_cfg < 0 && cfg == 0 && ((M + 127) / 128) * ((op.Cout + 127) / 128) < 128) cfg = 3;   // very few tiles: go finer
                 a.t_flops = 2.0 * op.macs * batch; a.t_bytes = op.bytes * batch;
+                if (d.wino && winograd) {
+                    // 36 GEMMs of depth Cin: short K loops, so the 128x32 tile (4 workgroups per CU) beats the 128x128 one
+                    // (IResNet-50, B = 128: 12.75 ms against 14.72 ms)
+                    const int wcfg = force_cfg >= 0 ? force_cfg : 2;
+                    launch_conv_winograd(a, P + d.w36, wino_v_.as<float>(), wino_m_.as<float>(), wcfg, s);
+                    tag = 7;
+                    break;
+                }
                 launch_conv(a, cfg, s);
                 tag = cfg;
                 break;

@@ -42,6 +42,7 @@ class Net {
     int in_h() const { return plan_.inH; }
     int in_w() const { return plan_.inW; }
     int capacity() const { return cap_; }
+    bool winograd = true;                                 // Winograd F(4x4,3x3) for the deep 3x3 convs (false: direct form everywhere)
     int cus = 0;                                          // CUs of the stream this net runs on when it is CU-masked (0 = all)
     int force_cfg = -1;                                   // tuning hook: conv tile config override
     bool sk_enable = true;                                // tuning hook: stream-K remainder wave
@@ -52,12 +53,15 @@ class Net {
         bool has_slope = false, has_aff = false;
         size_t w27 = 0;                                       // stem layout [27][Cout] (op 0 only)
         size_t dww = 0, dwb = 0;                              // fused depthwise front end (DWPW)
+        size_t w36 = 0;                                       // Winograd F(4,3) weights U[36][rows][Cin]
+        bool wino = false;                                    // eligible: 3x3 stride 1 pad 1, Cin >= 256
         int Kpad = 0;
     };
     float* tensor_ptr(int t) const { return arena_.as<float>() + plan_.tensors[t].offset * (size_t)cap_; }
     Plan plan_;
     std::vector<DevOp> dev_;
-    DevBuf params_, arena_, partial_;
+    DevBuf params_, arena_, partial_, wino_v_, wino_m_;
+    size_t wino_elems_ = 0;                                   // per image: 36 * tiles * max(Cin, Cout) of the largest Winograd op
     int cap_ = 0;
     bool stem_ok_ = false;
 };

@@ -14,7 +14,7 @@ void hip_check(hipError_t e, const char* what);
 // Optional per-launch HIP-event timing of the network kernels (bench.py's roofline leg).
 // Tags: 0..3 = conv_igemm tile configs, 4 = depthwise conv, 5 = other graph ops, 6 = conv stream-K fix-up.
 struct KernelTimer {
-    static constexpr int kTags = 7;
+    static constexpr int kTags = 9;      // 0-3 conv tile configs, 4 dw / dwpw, 5 other, 6 fix-up, 7 Winograd GEMM, 8 Winograd transforms
     bool enabled = false;
     void begin(hipStream_t s);
     void end(hipStream_t s, int tag, double flops, double bytes);
@@ -64,6 +64,10 @@ struct ConvArgs {
     int oact[3];
     int sk_enable;          // allow the stream-K remainder wave
     int cus;                // CUs this launch can occupy (0 = the whole device); sizes the stream-K remainder round
+    // grouped GEMM (Winograd: 36 independent [M x K] x [K x N] products in one launch): `groups` > 1, group g reads
+    // in + g*in_gs, wt + g*wt_gs and writes out1 + g*out_gs (strides in floats); tpg = tiles per group (filled in)
+    int groups, tpg;
+    long in_gs, wt_gs, out_gs;
     double t_flops, t_bytes; // algorithmic work of this launch (only used by the optional KernelTimer)
     // filled in by launch_conv: #plain tiles, K-chunk units dealt to helpers, units per helper, #helpers, #remainder
     // tiles, chunks each owner computes itself (0 = no owners: fix-up kernel), slab slots per remainder tile
@@ -77,6 +81,10 @@ void conv_workspace_init(float* ws);          // zero the counter words of a fre
 const float* conv_zero_line();                // 8 KiB of device zeros (target of padded / dead loads)
 // depthwise 3x3 stride 1 (+bias +act) fused with the 1x1 conv that consumes it (dwpw_mfma.hip)
 void launch_dwpw(const ConvArgs& a, hipStream_t s);
+// Winograd F(4x4,3x3) form of a 3x3 stride-1 pad-1 convolution (winograd.hip): a = the convolution's arguments,
+// wt36 = U[36][conv_wt_rows(Cout)][Cin], V / M = workspaces of 36 * tiles * max(Cin, Cout) floats each
+void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, hipStream_t s);
+void wino_filter_transform(const double g[9], double u[36]);     // host: G g G^T of one 3x3 filter
 int conv_wt_rows(int Cout);                   // packed weight rows (Cout rounded up to 128)
 size_t conv_slab_floats();
 // host: plan-layout weights [Cout][ks*ks][Cin] -> packed [conv_wt_rows(Cout)][conv_kpad(ks*ks*Cin)] (dst pre-zeroed)

@@ -1,0 +1,185 @@
+// winograd.hip — Winograd F(4x4, 3x3) for the deep 3x3 stride-1 convolutions (Cin >= 256) of IResNet.
+//
+// What it replaces: the same Conv nodes conv_mfma.hip computes directly (reference: ORT inside session_->Run,
+// src/face_recognizer.cpp:279-283).  Y = A^T [ (G g G^T) (.) (B^T d B) ] A on 4x4 output tiles: 36 multiplies per
+// 16 outputs and input channel instead of 144 — the matrix-core work of these layers drops 4x, at the price of two
+// bandwidth-bound transform passes and of fp32 rounding errors ~25x those of the direct form (measured in
+// DESIGN.md; far inside the path's tolerance, but it is why the direct kernel stays the default for thin layers
+// and why the switch fh_rec_set_winograd exists).
+//
+//   wino_input_kernel   d (6x6 input patch per tile, zero padded)  ->  V[f][tile][ci] = B^T d B, f = 6*i + j
+//   conv_igemm_kernel   36 independent GEMMs in ONE grouped launch:  M[f] = V[f] (tiles x Cin) * U[f] (Cin x Cout)
+//   wino_output_kernel  Y = A^T M A, + bias -> PReLU / ReLU -> (+ residual) -> out, optional second output y*s2+t2
+//
+// U[f] = G g G^T is computed once at load time in fp64 (engine.cpp).  Interpolation points 0, +-1, +-2, inf
+// (Lavin & Gray 2016).  Thread = one tile x 4 channels; every load / store is a 16-byte lane access and
+// consecutive lanes walk the channels, so all transfers are whole 128-byte lines.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "plan.h"
+
+namespace fh {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// B^T (6x6) applied to a 6-vector
+__device__ __forceinline__ void wino_bt(const v4f (&d)[6], v4f (&t)[6]) {
+    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    t[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
+    t[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
+    t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+    t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+// A^T (4x6) applied to a 6-vector
+__device__ __forceinline__ void wino_at(const v4f (&m)[6], v4f (&y)[4]) {
+    y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    y[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+    y[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+    y[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+}
+
+// in [B,H,W,C] -> V [36][NT][C], NT = B*TY*TX tiles of 4x4 outputs (input patch rows 4ty-1 .. 4ty+4)
+__global__ __launch_bounds__(256, 2) void wino_input_kernel(const float* __restrict__ in, float* __restrict__ V, int B, int H, int W,
+                                                            int C, int TY, int TX) {
+    const int C4 = C >> 2;
+    const long NT = (long)B * TY * TX;
+    const long total = NT * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const long tile = idx / C4;
+        const int tx = (int)(tile % TX), ty = (int)((tile / TX) % TY), b = (int)(tile / ((long)TX * TY));
+        const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
+        const float* img = in + (size_t)b * H * W * C + c4 * 4;
+        v4f t[6][6];                                         // t[i][c] = (B^T d)[i][c]: columns of the patch first
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int ix = ix0 + c;
+            v4f d[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const int iy = iy0 + r;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                d[r] = ok ? *reinterpret_cast<const v4f*>(img + ((size_t)iy * W + ix) * C) : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+            v4f tc[6];
+            wino_bt(d, tc);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][c] = tc[i];
+        }
+        float* dst = V + (size_t)tile * C + c4 * 4;
+        const size_t fs = (size_t)NT * C;                    // stride between frequency planes
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            v4f o[6];
+            wino_bt(t[i], o);                                // (B^T d B)[i][j] = sum_c (B^T d)[i][c] * B^T[j][c]
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(dst + (size_t)(i * 6 + j) * fs) = o[j];
+        }
+    }
+}
+
+struct WinoOutArgs {
+    const float* M; const float* bias; const float* slope; const float* res; float* out1; float* out2; const float* s2; const float* t2;
+    int B, H, W, C, TY, TX, act;
+};
+
+// M [36][NT][C] -> out [B,H,W,C] (H x W = output grid = input grid), epilogue as conv_mfma.hip's
+__global__ __launch_bounds__(256, 2) void wino_output_kernel(const WinoOutArgs p) {
+    const int C = p.C, C4 = C >> 2;
+    const long NT = (long)p.B * p.TY * p.TX;
+    const long total = NT * C4;
+    const size_t fs = (size_t)NT * C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const long tile = idx / C4;
+        const int tx = (int)(tile % p.TX), ty = (int)((tile / p.TX) % p.TY), b = (int)(tile / ((long)p.TX * p.TY));
+        const float* src = p.M + (size_t)tile * C + c4 * 4;
+        v4f t[4][6];                                         // t[y][j] = (A^T M)[y][j]
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            v4f m[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const v4f*>(src + (size_t)(i * 6 + j) * fs);
+            v4f y[4];
+            wino_at(m, y);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r][j] = y[r];
+        }
+        const v4f b4 = p.bias ? *reinterpret_cast<const v4f*>(p.bias + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+        v4f sl = {0.f, 0.f, 0.f, 0.f}, s2 = sl, t2 = sl;
+        if (p.act == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(p.slope + c4 * 4);
+        if (p.out2) { s2 = *reinterpret_cast<const v4f*>(p.s2 + c4 * 4); t2 = *reinterpret_cast<const v4f*>(p.t2 + c4 * 4); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oy = 4 * ty + r;
+            if (oy >= p.H) continue;
+            v4f y[4];
+            wino_at(t[r], y);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int ox = 4 * tx + x;
+                if (ox >= p.W) continue;
+                v4f v = y[x] + b4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float u = v[e];
+                    if (p.act == (int)Act::RELU) u = u > 0.f ? u : 0.f;
+                    else if (p.act == (int)Act::PRELU) u = u >= 0.f ? u : u * sl[e];
+                    else if (p.act == (int)Act::SIGMOID) u = 1.0f / (1.0f + expf(-u));
+                    v[e] = u;
+                }
+                const size_t o = (((size_t)b * p.H + oy) * p.W + ox) * C + c4 * 4;
+                if (p.res) v += *reinterpret_cast<const v4f*>(p.res + o);
+                if (p.out1) *reinterpret_cast<v4f*>(p.out1 + o) = v;
+                if (p.out2) *reinterpret_cast<v4f*>(p.out2 + o) = v * s2 + t2;
+            }
+        }
+    }
+}
+
+static inline int wino_grid(long n) {
+    const long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : b > 256 * 16 ? 256 * 16 : b);
+}
+
+// G g G^T of one 3x3 filter in fp64: g[ky][kx] -> u[36] (f = 6*i + j)
+void wino_filter_transform(const double g[9], double u[36]) {
+    static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+    double t[6][3];
+    for (int i = 0; i < 6; ++i)
+        for (int kx = 0; kx < 3; ++kx) t[i][kx] = G[i][0] * g[0 * 3 + kx] + G[i][1] * g[1 * 3 + kx] + G[i][2] * g[2 * 3 + kx];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) u[i * 6 + j] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
+}
+
+// a: the convolution's arguments (in, bias, slope, res, out1, out2, s2, t2, B, H, W, Cin, Cout, act, slabs, ...);
+// wt36 = 36 packed weight images [conv_wt_rows(Cout)][Cin] (U[f]), V / M = workspaces of 36 * tiles * max(Cin, Cout) floats.
+void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, hipStream_t s) {
+    const int TY = (a.H + 3) / 4, TX = (a.W + 3) / 4;
+    const long NT = (long)a.B * TY * TX;
+    if (NT <= 0) return;
+    KernelTimer& timer = KernelTimer::get();
+    timer.begin(s);
+    hipLaunchKernelGGL(wino_input_kernel, dim3(wino_grid(NT * (a.Cin >> 2))), dim3(256), 0, s, a.in, V, a.B, a.H, a.W, a.Cin, TY, TX);
+    timer.end(s, 8, 0.0, 0.0);
+    ConvArgs g{};
+    g.in = V; g.wt = wt36; g.out1 = M; g.slabs = a.slabs; g.sk_enable = a.sk_enable; g.cus = a.cus;
+    g.B = (int)NT; g.H = g.W = g.Ho = g.Wo = 1; g.Cin = a.Cin; g.Cout = a.Cout; g.ks = 1; g.stride = 1; g.pad = 0; g.Kpad = a.Cin;
+    g.act = (int)Act::NONE; g.res_mode = (int)ResMode::NONE;
+    g.groups = 36; g.in_gs = NT * a.Cin; g.wt_gs = (long)conv_wt_rows(a.Cout) * a.Cin; g.out_gs = NT * a.Cout;
+    // booked on the GEMM: the FLOPs it EXECUTES (physical matrix-core utilisation) and, in the bytes slot of the timer, the
+    // direct-form FLOPs of the convolution it stands for (the algorithmic figure bench.py quotes beside it)
+    g.t_flops = 2.0 * 36.0 * (double)NT * a.Cin * a.Cout; g.t_bytes = a.t_flops;
+    launch_conv(g, cfg, s);
+    WinoOutArgs o{};
+    o.M = M; o.bias = a.bias; o.slope = a.slope; o.res = a.res; o.out1 = a.out1; o.out2 = a.out2; o.s2 = a.s2; o.t2 = a.t2;
+    o.B = a.B; o.H = a.H; o.W = a.W; o.C = a.Cout; o.TY = TY; o.TX = TX; o.act = a.act;
+    timer.begin(s);
+    hipLaunchKernelGGL(wino_output_kernel, dim3(wino_grid(NT * (a.Cout >> 2))), dim3(256), 0, s, o);
+    timer.end(s, 8, 0.0, 0.0);
+}
+
+}  // namespace fh

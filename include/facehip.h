@@ -144,8 +144,9 @@ FH_API int fh_gallery_label_dev(fh_gallery* g, const float* d_queries, int nq, f
                                 float* d_scores, void* stream);
 
 /* ---- measurement hooks (bench.py): per-launch HIP-event timing of the network kernels.
- * Tags 0..3 = conv_igemm tile configs (128x128, 256x64, 128x32, 64x64), 4 = depthwise conv,
- * 5 = other graph ops, 6 = conv stream-K fix-up.  fh_timing_collect synchronises, fills 7-entry arrays (elapsed ms,
+ * Tags 0..3 = conv_igemm tile configs (128x128, 256x64, 128x32, 64x64), 4 = depthwise / depthwise+pointwise,
+ * 5 = other graph ops, 6 = conv stream-K fix-up, 7 = Winograd GEMM (its FLOPs = executed; bytes slot = the layer's
+ * direct-form FLOPs), 8 = Winograd transforms.  fh_timing_collect synchronises, fills 9-entry arrays (elapsed ms,
  * algorithmic FLOP, algorithmic activation bytes, launches) and resets the counters.
  * fh_*_set_conv_cfg forces one tile config for every dense conv of a handle (-1 = automatic)
  * and switches the stream-K remainder wave on/off (tuning / A-B measurements). */
@@ -156,6 +157,10 @@ FH_API int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k);
 FH_API int fh_rec_set_conv_cfg(fh_rec* r, int cfg, int stream_k);
 /* on (default): the u8 preprocess is fused into the first convolution and the preprocessed input tensor is
  * never materialised; off: separate preprocess kernel (needed for fh_det_input_dev). */
+/* 3x3 stride-1 convolutions with >= 256 input channels run as Winograd F(4x4,3x3) (a quarter of the matrix-core work,
+ * fp32 rounding error ~25x the direct form's: see DESIGN.md) unless switched off here; 0 = direct form everywhere. */
+FH_API int fh_det_set_winograd(fh_det* d, int on);
+FH_API int fh_rec_set_winograd(fh_rec* r, int on);
 /* A handle whose stream is restricted to a subset of the CUs (hipExtStreamCreateWithCUMask, e.g. detector and
  * recogniser side by side on disjoint CU sets) should say how many it gets: it sizes the convolution kernels'
  * remainder round.  0 = the whole device (default). */
@@ -178,6 +183,10 @@ FH_API int fh_resize_u8c3_dev(const uint8_t* d_src, int sh, int sw, int sstep, u
                               void* stream);
 FH_API int fh_conv_forward_dev(const float* d_in, const float* d_wt_packed, const float* d_bias, float* d_out, int batch,
                                int h, int w, int cin, int cout, int ksize, int stride, int kpad, int cfg, void* stream);
+/* 3x3 stride-1 pad-1 convolution (+bias) in the Winograd F(4x4,3x3) form the deep layers use; w_ohwi = HOST weights
+ * [cout][3*3][cin]; cin % 32 == 0, cout % 4 == 0.  Synchronous. */
+FH_API int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi_host, const float* d_bias, float* d_out, int batch, int h, int w,
+                                int cin, int cout, void* stream);
 FH_API int fh_conv_wt_rows(int cout);
 /* host: weights [cout][ksize*ksize][cin] (O,H,W,I) -> the kernel's packed image [fh_conv_wt_rows][fh_conv_kpad] */
 FH_API int fh_conv_pack_weights(const float* w_ohwi, int cout, int cin, int ksize, float* dst_packed);

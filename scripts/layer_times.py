@@ -41,8 +41,8 @@ oi = 0
 for i in range(per):
     t = np.median([ms[r * per + i] for r in range(R)])
     tot += t
-    if tg[i] == 6:
-        print(f"{t*1e3:9.1f} us             fix-up")
+    if tg[i] in (6, 8):
+        print(f"{t*1e3:9.1f} us             {'fix-up' if tg[i] == 6 else 'winograd transform'}")
         continue
     print(f"{t*1e3:9.1f} us  {fl[i]/t/1e9 if t>0 else 0:7.1f} TF/s  cfg{tg[i]}  {ops[oi] if oi < len(ops) else ''}")
     oi += 1

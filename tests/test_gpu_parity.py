@@ -123,6 +123,56 @@ def test_depthwise_pointwise_block_matches_oracle(tmp_path, H, W, Cc, Cout, ds):
         np.testing.assert_allclose(got[i], ref.reshape(got[i].shape), rtol=1e-5, atol=2e-5)
 
 
+WINO_CASES = [
+    # B, H,  W,  Cin, Cout      (ragged H / W: tiles of 4x4 outputs hang over the border)
+    (2, 14, 14, 256, 256),
+    (3, 7, 7, 512, 128),
+    (1, 28, 28, 128, 128),
+    (2, 13, 10, 128, 64),
+    (1, 5, 9, 160, 36),
+    (1, 4, 4, 128, 32),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", WINO_CASES)
+def test_winograd_conv_matches_oracle(B, H, W, Cin, Cout):
+    """Winograd F(4x4,3x3) form of the deep 3x3 stride-1 convolutions (winograd.hip) vs the oracle's direct convolution.
+    fp32 Winograd with points 0, +-1, +-2, inf rounds ~25x coarser than the direct form: 2e-4 absolute on O(1) outputs."""
+    rng = np.random.default_rng(B * 1000 + H * 10 + Cin)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = oracle.conv2d(x, w, b, 1, 1, 1)
+    ohwi = np.ascontiguousarray(w.transpose(0, 2, 3, 1))                    # [Cout][3][3][Cin]
+    xd, bd = dev(x.transpose(0, 2, 3, 1)), dev(b)
+    out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    rc = fa.lib().fh_conv_winograd_dev(xd.data_ptr(), ohwi.ctypes.data, bd.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, 0)
+    assert rc == 0, _lib.last_error()
+    got = out.cpu().numpy().transpose(0, 3, 1, 2)
+    assert np.isfinite(got).all()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-4)
+    assert np.sqrt(((got - ref) ** 2).mean()) < 2e-5                        # rms error stays at the 1e-5 level
+
+
+def test_winograd_switch_changes_only_rounding():
+    """Full-size IResNet-50 with and without the Winograd form of its 128+-channel 3x3 convolutions."""
+    from facerecognizeonnx_amd.synth import models
+    rec = fa.FaceRecognizer()
+    assert rec.loadModel(models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50))
+    n = 24
+    crops = dev(util.frames_u8(n, 112, 112, seed=21))
+    res = []
+    for on in (1, 0):
+        assert fa.lib().fh_rec_set_winograd(rec.handle, on) == 0
+        raw = torch.zeros((n, 512), device="cuda"); out = torch.zeros((n, 512), device="cuda")
+        assert rec.embed_aligned_dev(crops.data_ptr(), n, out.data_ptr(), raw.data_ptr()) == n
+        torch.cuda.synchronize()
+        res.append((raw.cpu().numpy().astype(np.float64), out.cpu().numpy().astype(np.float64)))
+    (r1, e1), (r0, e0) = res
+    assert np.abs(r1 - r0).max() / np.abs(r0).max() < 1e-4                  # raw outputs: relative to their scale
+    assert (1.0 - (e1 * e0).sum(1)).max() < 1e-6                            # embeddings: cosine
+
+
 def test_det_preprocess_bit_exact(models_dir):
     det = fa.FaceDetector()
     assert det.loadModel(util.tiny_scrfd(models_dir, hw=128))
