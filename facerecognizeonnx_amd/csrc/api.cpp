@@ -391,7 +391,7 @@ int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi, const float* d_
         a.in = d_in; a.bias = d_bias; a.out1 = d_out; a.slabs = slabs.as<float>(); a.sk_enable = 1;
         a.B = batch; a.H = h; a.W = w; a.Ho = h; a.Wo = w; a.Cin = cin; a.Cout = cout; a.ks = 3; a.stride = 1; a.pad = 1;
         a.act = (int)fh::Act::NONE; a.res_mode = (int)fh::ResMode::NONE;
-        fh::launch_conv_winograd(a, dU.as<float>(), dV.as<float>(), dM.as<float>(), 2, S(stream));
+        fh::launch_conv_winograd(a, dU.as<float>(), dV.as<float>(), dM.as<float>(), 2, nullptr, nullptr, S(stream));
         FH_HIP(hipStreamSynchronize(S(stream)));                 // the workspaces die with this scope
         return 0;
     });

@@ -229,11 +229,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
         int tl = tile;
         const float* g_in = p.in;
         const float* g_wt = p.wt;
-        long g_out = 0;
         if (GRP && p.tpg > 0) {
             const int g = tile / p.tpg;
             tl = tile - g * p.tpg;
-            g_in += (size_t)g * p.in_gs; g_wt += (size_t)g * p.wt_gs; g_out = (long)g * p.out_gs;
+            g_in += (size_t)g * p.in_gs; g_wt += (size_t)g * p.wt_gs;
         }
         const int tile_n = tl % tiles_n, tile_m = tl / tiles_n;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -429,7 +428,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                         }
             }
         }
-        conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane, -1, -1, g_out);
+        // (the group's output offset is recomputed here rather than kept live across the main loop)
+        conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane, -1, -1, (GRP && p.tpg > 0) ? (long)(tile / p.tpg) * p.out_gs : 0L);
     } while (role == HELPER && hu < hu_end);
 }
 

@@ -131,6 +131,20 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
         if (!op.slope.empty()) { d.slope = push(op.slope.data(), op.slope.size()); d.has_slope = true; }
         if (!op.s2.empty()) { d.s2 = push(op.s2.data(), op.s2.size()); d.t2 = push(op.t2.data(), op.t2.size()); d.has_aff = true; }
     }
+    // A Winograd conv that is the only reader of its producer's BatchNorm'ed second output takes the producer's plain output
+    // instead and lets its input transform apply the affine (exact: padding stays zero): the second output is never written.
+    for (size_t i = 0; i < plan_.ops.size(); ++i) {
+        if (!dev_[i].wino) continue;
+        const int t = plan_.ops[i].in;
+        int uses = 0, prod = -1;
+        for (size_t j = 0; j < plan_.ops.size(); ++j) {
+            const POp& o = plan_.ops[j];
+            for (int x : {o.in, o.in2, o.res}) if (x == t) ++uses;
+            if (o.out2 == t && o.out >= 0 && (o.kind == OpKind::CONV) && j < i) prod = (int)j;
+        }
+        for (const auto& o : plan_.outputs) if (o.tensor == t) ++uses;
+        if (prod > 0 && uses == 1 && dev_[prod].has_aff) { dev_[i].aff_src = prod; dev_[prod].aff_dst = (int)i; }   // (op 0 = the stem keeps its own path)
+    }
     {   // can the first conv take the u8 image directly?  (3x3, Cin = 3 stored as 4, plain epilogue)
         const POp& op = plan_.ops[0];
         stem_ok_ = op.kind == OpKind::CONV && op.in == plan_.input && op.ks == 3 && op.Cin == 4 && op.res < 0 && op.outs.empty() &&
@@ -207,6 +221,7 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 a.res = op.res >= 0 ? tensor_ptr(op.res) : nullptr;
                 a.out1 = op.out >= 0 ? tensor_ptr(op.out) : nullptr;
                 a.out2 = op.out2 >= 0 ? tensor_ptr(op.out2) : nullptr;
+                if (d.aff_dst >= 0 && winograd) a.out2 = nullptr;          // its only reader applies the BatchNorm itself (see aff_src)
                 a.s2 = d.has_aff ? P + d.s2 : nullptr;
                 a.t2 = d.has_aff ? P + d.t2 : nullptr;
                 a.slabs = partial_.as<float>();
@@ -226,7 +241,12 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                     // 36 GEMMs of depth Cin: short K loops, so the 128x32 tile (4 workgroups per CU) beats the 128x128 one
                     // (IResNet-50, B = 128: 12.75 ms against 14.72 ms)
                     const int wcfg = force_cfg >= 0 ? force_cfg : 2;
-                    launch_conv_winograd(a, P + d.w36, wino_v_.as<float>(), wino_m_.as<float>(), wcfg, s);
+                    const float* in_s = nullptr; const float* in_t = nullptr;
+                    if (d.aff_src >= 0) {
+                        a.in = tensor_ptr(plan_.ops[d.aff_src].out);
+                        in_s = P + dev_[d.aff_src].s2; in_t = P + dev_[d.aff_src].t2;
+                    }
+                    launch_conv_winograd(a, P + d.w36, wino_v_.as<float>(), wino_m_.as<float>(), wcfg, in_s, in_t, s);
                     tag = 7;
                     break;
                 }

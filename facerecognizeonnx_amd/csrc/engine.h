@@ -54,7 +54,10 @@ class Net {
         size_t w27 = 0;                                       // stem layout [27][Cout] (op 0 only)
         size_t dww = 0, dwb = 0;                              // fused depthwise front end (DWPW)
         size_t w36 = 0;                                       // Winograd F(4,3) weights U[36][rows][Cin]
-        bool wino = false;                                    // eligible: 3x3 stride 1 pad 1, Cin >= 256
+        bool wino = false;                                    // eligible: 3x3 stride 1 pad 1, Cin >= 128
+        int aff_src = -1;                                     // Winograd op whose input is op[aff_src]'s second (BatchNorm) output and its only
+                                                              // consumer: the transform reads op[aff_src].out and applies that affine itself
+        int aff_dst = -1;                                     // ... and the producer's side of the same link
         int Kpad = 0;
     };
     float* tensor_ptr(int t) const { return arena_.as<float>() + plan_.tensors[t].offset * (size_t)cap_; }

@@ -83,7 +83,9 @@ const float* conv_zero_line();                // 8 KiB of device zeros (target o
 void launch_dwpw(const ConvArgs& a, hipStream_t s);
 // Winograd F(4x4,3x3) form of a 3x3 stride-1 pad-1 convolution (winograd.hip): a = the convolution's arguments,
 // wt36 = U[36][conv_wt_rows(Cout)][Cin], V / M = workspaces of 36 * tiles * max(Cin, Cout) floats each
-void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, hipStream_t s);
+// in_scale / in_shift (optional): per-input-channel affine applied to in-image pixels by the input transform
+void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, const float* in_scale, const float* in_shift,
+                          hipStream_t s);
 void wino_filter_transform(const double g[9], double u[36]);     // host: G g G^T of one 3x3 filter
 int conv_wt_rows(int Cout);                   // packed weight rows (Cout rounded up to 128)
 size_t conv_slab_floats();

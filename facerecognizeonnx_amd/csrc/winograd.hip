@@ -41,8 +41,11 @@ __device__ __forceinline__ void wino_at(const v4f (&m)[6], v4f (&y)[4]) {
 }
 
 // in [B,H,W,C] -> V [36][NT][C], NT = B*TY*TX tiles of 4x4 outputs (input patch rows 4ty-1 .. 4ty+4)
+// aff_s / aff_t (optional): per-channel affine applied to the in-image pixels only — the block's pre-conv BatchNorm, so that the
+// producer need not write a normalised copy of its output (zero padding stays exactly zero).
 __global__ __launch_bounds__(256, 2) void wino_input_kernel(const float* __restrict__ in, float* __restrict__ V, int B, int H, int W,
-                                                            int C, int TY, int TX) {
+                                                            int C, int TY, int TX, const float* __restrict__ aff_s,
+                                                            const float* __restrict__ aff_t) {
     const int C4 = C >> 2;
     const long NT = (long)B * TY * TX;
     const long total = NT * C4;
@@ -52,6 +55,8 @@ __global__ __launch_bounds__(256, 2) void wino_input_kernel(const float* __restr
         const int tx = (int)(tile % TX), ty = (int)((tile / TX) % TY), b = (int)(tile / ((long)TX * TY));
         const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
         const float* img = in + (size_t)b * H * W * C + c4 * 4;
+        v4f as4 = {1.f, 1.f, 1.f, 1.f}, at4 = {0.f, 0.f, 0.f, 0.f};
+        if (aff_s) { as4 = *reinterpret_cast<const v4f*>(aff_s + c4 * 4); at4 = *reinterpret_cast<const v4f*>(aff_t + c4 * 4); }
         v4f t[6][6];                                         // t[i][c] = (B^T d)[i][c]: columns of the patch first
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void wino_input_kernel(const float* __restr
             for (int r = 0; r < 6; ++r) {
                 const int iy = iy0 + r;
                 const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                d[r] = ok ? *reinterpret_cast<const v4f*>(img + ((size_t)iy * W + ix) * C) : v4f{0.f, 0.f, 0.f, 0.f};
+                d[r] = ok ? *reinterpret_cast<const v4f*>(img + ((size_t)iy * W + ix) * C) * as4 + at4 : v4f{0.f, 0.f, 0.f, 0.f};
             }
             v4f tc[6];
             wino_bt(d, tc);
@@ -157,13 +162,15 @@ void wino_filter_transform(const double g[9], double u[36]) {
 
 // a: the convolution's arguments (in, bias, slope, res, out1, out2, s2, t2, B, H, W, Cin, Cout, act, slabs, ...);
 // wt36 = 36 packed weight images [conv_wt_rows(Cout)][Cin] (U[f]), V / M = workspaces of 36 * tiles * max(Cin, Cout) floats.
-void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, hipStream_t s) {
+void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, const float* in_scale, const float* in_shift,
+                          hipStream_t s) {
     const int TY = (a.H + 3) / 4, TX = (a.W + 3) / 4;
     const long NT = (long)a.B * TY * TX;
     if (NT <= 0) return;
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
-    hipLaunchKernelGGL(wino_input_kernel, dim3(wino_grid(NT * (a.Cin >> 2))), dim3(256), 0, s, a.in, V, a.B, a.H, a.W, a.Cin, TY, TX);
+    hipLaunchKernelGGL(wino_input_kernel, dim3(wino_grid(NT * (a.Cin >> 2))), dim3(256), 0, s, a.in, V, a.B, a.H, a.W, a.Cin, TY, TX, in_scale,
+                       in_shift);
     timer.end(s, 8, 0.0, 0.0);
     ConvArgs g{};
     g.in = V; g.wt = wt36; g.out1 = M; g.slabs = a.slabs; g.sk_enable = a.sk_enable; g.cus = a.cus;
