@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 CFG_NAMES = ["conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<256,64,4,1>", "conv_igemm_kernel<128,32,4,1>",
              "conv_igemm_kernel<64,64,2,2>", "dwpw_kernel + dwconv3x3 kernels", "other graph ops (incl. stem_conv_u8)", "conv_fixup_kernel",
-             "conv_igemm_kernel<128,32,4,1> as Winograd F(4x4,3x3) GEMM (36 groups)", "wino_input_kernel + wino_output_kernel"]
+             "conv_igemm_kernel<128,32,4,1> grouped (Winograd GEMM)", "wino_input_kernel + wino_output_kernel"]
 NTAGS = len(CFG_NAMES)
 
 

@@ -35,7 +35,8 @@ def short(name):
     base, targs = m.group(1), m.group(2) or ""
     if base == "conv_igemm_kernel":
         a = [x.strip() for x in targs.strip("<>").split(",")]
-        return f"conv_igemm_kernel<{a[0]},{a[1]},{a[2]},{a[3]}>"
+        grouped = len(a) > 6 and a[6] == "true"              # the 36-GEMM launch of the Winograd form
+        return f"conv_igemm_kernel<{a[0]},{a[1]},{a[2]},{a[3]}>" + (" grouped (Winograd GEMM)" if grouped else "")
     if base == "conv_fixup_kernel":
         return "conv_fixup_kernel"
     return base + (targs if len(targs) < 24 else "")
