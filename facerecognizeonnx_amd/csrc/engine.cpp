@@ -70,6 +70,7 @@ int KernelTimer::collect_ops(double* ms, double* flops, int* tag, int cap) {
 // Winograd pays from 128 input channels on (IResNet-50, B = 128: 14.13 ms direct, 11.2 ms with >= 256, 10.5 ms with >= 128,
 // 10.6 ms with >= 64: below 128 the two transform passes cost what the matrix cores save)
 static constexpr int kWinoMinCin = 128;
+static constexpr long kWinoMinTiles = 256;      // 4x4-output tiles per launch below which the direct form is used
 
 Net::Net(const std::string& onnx_path, int default_h, int default_w) {
     OnnxModel m = load_onnx(onnx_path);
@@ -221,7 +222,10 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 a.res = op.res >= 0 ? tensor_ptr(op.res) : nullptr;
                 a.out1 = op.out >= 0 ? tensor_ptr(op.out) : nullptr;
                 a.out2 = op.out2 >= 0 ? tensor_ptr(op.out2) : nullptr;
-                if (d.aff_dst >= 0 && winograd) a.out2 = nullptr;          // its only reader applies the BatchNorm itself (see aff_src)
+                if (d.aff_dst >= 0 && winograd) {                          // its only reader applies the BatchNorm itself (see aff_src)
+                    const POp& c = plan_.ops[d.aff_dst];
+                    if ((long)batch * ((c.H + 3) / 4) * ((c.W + 3) / 4) >= kWinoMinTiles) a.out2 = nullptr;
+                }
                 a.s2 = d.has_aff ? P + d.s2 : nullptr;
                 a.t2 = d.has_aff ? P + d.t2 : nullptr;
                 a.slabs = partial_.as<float>();
@@ -237,7 +241,10 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 int cfg = force_cfg >= 0 ? force_cfg : conv_pick_cfg(M, op.Cout);
                 if (force_cfg < 0 && cfg == 0 && ((M + 127) / 128) * ((op.Cout + 127) / 128) < 128) cfg = 3;   // very few tiles: go finer
                 a.t_flops = 2.0 * op.macs * batch; a.t_bytes = op.bytes * batch;
-                if (d.wino && winograd) {
+                // (small batches: the 36 GEMMs would be mostly tile padding and the direct form with split-K is faster —
+                //  measured cross-over at 256 tiles per GEMM: B = 1: 0.98 ms direct / 1.83 ms Winograd, B = 32: 4.82 / 3.88)
+                const bool use_wino = d.wino && winograd && (long)batch * ((op.H + 3) / 4) * ((op.W + 3) / 4) >= kWinoMinTiles;
+                if (use_wino) {
                     // 36 GEMMs of depth Cin: short K loops, so the 128x32 tile (4 workgroups per CU) beats the 128x128 one
                     // (IResNet-50, B = 128: 12.75 ms against 14.72 ms)
                     const int wcfg = force_cfg >= 0 ? force_cfg : 2;
