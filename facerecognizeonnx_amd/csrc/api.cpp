@@ -382,8 +382,8 @@ int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi, const float* d_
         const size_t tiles = (size_t)batch * ((h + 3) / 4) * ((w + 3) / 4);
         fh::DevBuf dU, dV, dM;
         dU.ensure(u36.size() * sizeof(float));
-        dV.ensure(36 * tiles * cin * sizeof(float));
-        dM.ensure(36 * tiles * cout * sizeof(float));
+        dV.ensure(36 * (size_t)fh::wino_rows((long)tiles) * cin * sizeof(float));
+        dM.ensure(36 * (size_t)fh::wino_rows((long)tiles) * cout * sizeof(float));
         FH_HIP(hipMemcpy(dU.p, u36.data(), u36.size() * sizeof(float), hipMemcpyHostToDevice));
         static fh::DevBuf slabs;
         if (!slabs.p) { slabs.ensure(fh::conv_slab_floats() * sizeof(float)); fh::conv_workspace_init(slabs.as<float>()); }

@@ -83,13 +83,13 @@ struct Tile {
 // C/D map of the 32x32 MFMA: column (= pixel here) = lane & 31, row (= channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0,
-                                              int wm, int wn, int lane, int only_i = -1, int only_j = -1, long out_off = 0) {
+                                              int wm, int wn, int lane, int only_i = -1, int only_j = -1) {
     using TL = Tile<BM, BN, WM, WN>;
     const int fr = lane & 31, fh2 = lane >> 5;
     const int HoWo = p.Ho * p.Wo;
     const int M = p.B * HoWo;
     const float* __restrict__ res = p.res;
-    float* __restrict__ out1 = p.out1 ? p.out1 + out_off : nullptr;   // (out_off: grouped GEMM, see ConvArgs::tpg)
+    float* __restrict__ out1 = p.out1;
     float* __restrict__ out2 = p.out2;
     const bool vec = (p.Cout & 3) == 0;
     if (p.n_outs > 0) {                                  // merged sibling convs: per-channel-range destination
@@ -225,17 +225,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
             part = helper_id - (r * Kh) / p.sk_q;           // position among the helpers that touch this tile
             hu += len;
         }
-        // grouped form (Winograd's 36 independent GEMMs): tile -> (group, tile inside the group), per-group operand bases
-        int tl = tile;
-        const float* g_in = p.in;
-        const float* g_wt = p.wt;
-        if (GRP && p.tpg > 0) {
-            const int g = tile / p.tpg;
-            tl = tile - g * p.tpg;
-            g_in += (size_t)g * p.in_gs; g_wt += (size_t)g * p.wt_gs;
-        }
-        const int tile_n = tl % tiles_n, tile_m = tl / tiles_n;
+        const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
+        // grouped form (Winograd's 36 GEMMs stacked along M, wt_group_rows rows each, a multiple of BM): only the weight
+        // matrix depends on the group — inputs and outputs are one tall matrix
+        const float* g_wt = p.wt;
+        if (GRP && p.wt_group_rows > 0) g_wt += (size_t)(m0 / p.wt_group_rows) * p.wt_gs;
 
         // ---- loader bookkeeping.  LDS-DMA (global_load_lds_dwordx4) writes lane l of a wave at
         // wave-uniform base + 16*l, i.e. pass i of wave `wid` fills rows i*RP + wid*8 + (l>>3), 16-byte
@@ -251,7 +246,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                 const int n = m / HoWo, rem = m - n * HoWo;
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-                a_ptr[i] = g_in + (long)(((n * p.H + iy0) * p.W + ix0) * p.Cin) + lqs * 4;
+                a_ptr[i] = p.in + (long)(((n * p.H + iy0) * p.W + ix0) * p.Cin) + lqs * 4;
                 unsigned mk = 0;
                 if (p.ks == 3) {
 #pragma unroll
@@ -428,8 +423,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                         }
             }
         }
-        // (the group's output offset is recomputed here rather than kept live across the main loop)
-        conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane, -1, -1, (GRP && p.tpg > 0) ? (long)(tile / p.tpg) * p.out_gs : 0L);
+        conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
     } while (role == HELPER && hu < hu_end);
 }
 
@@ -471,11 +465,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             if (i == si && j == sj) acc[i][j] = sum;
-    int tl = tile;
-    long g_out = 0;
-    if (p.tpg > 0) { const int g = tile / p.tpg; tl = tile - g * p.tpg; g_out = (long)g * p.out_gs; }
-    const int tile_n = tl % tiles_n, tile_m = tl / tiles_n;
-    conv_epilogue<BM, BN, WM, WN>(p, acc, tile_m * BM, tile_n * BN, wm, wn, lane, si, sj, g_out);
+    const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+    conv_epilogue<BM, BN, WM, WN>(p, acc, tile_m * BM, tile_n * BN, wm, wn, lane, si, sj);
 }
 
 int conv_wt_rows(int Cout) { return (Cout + 127) / 128 * 128; }
@@ -548,9 +539,8 @@ template <int BM, int BN, int WM, int WN, int OCC>
 static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t s) {
     const long M = (long)a.B * a.Ho * a.Wo;
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (a.Cout + BN - 1) / BN;
-    const int groups = a.groups > 1 ? a.groups : 1;
-    a.tpg = groups > 1 ? tiles_m * tiles_n : 0;
-    const int T = tiles_m * tiles_n * groups;
+    const bool grouped = a.wt_group_rows > 0;
+    const int T = tiles_m * tiles_n;
     const int chunks = a.Kpad / 32;
     const int S = (a.cus > 0 ? a.cus : num_cus()) * resident_per_cu;
     a.zeros = conv_zero_line();
@@ -592,14 +582,13 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
     const dim3 grid((unsigned)(full + helpers + owners));
-    if (groups > 1) {
-        if ((a.Cin & 31) != 0) { a.tpg = 0; }                  // (callers only group 32-aligned depths; never reached)
+    if (grouped) {                                             // (wt_group_rows % BM == 0 and Cin % 32 == 0: the caller's contract)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true, true>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
     } else if ((a.Cin & 31) == 0)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true, false>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
     else
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, false, false>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
-    timer.end(s, a.groups > 1 ? 7 : cfg_tag, a.t_flops, a.t_bytes);   // (grouped = Winograd GEMM: its own tag)
+    timer.end(s, grouped ? 7 : cfg_tag, a.t_flops, a.t_bytes);   // (grouped = Winograd GEMM: its own tag)
     if (fixup) {
         timer.begin(s);
         hipLaunchKernelGGL((conv_fixup_kernel<BM, BN, WM, WN>), dim3((unsigned)(R * (BM / WM / 32) * (BN / WN / 32))), dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);

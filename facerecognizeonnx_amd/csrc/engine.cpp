@@ -124,6 +124,7 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
                 d.wino = true;
                 const size_t tiles = (size_t)((op.H + 3) / 4) * ((op.W + 3) / 4);
                 wino_elems_ = std::max(wino_elems_, 36 * tiles * (size_t)std::max(op.Cin, op.Cout));
+                wino_maxc_ = std::max(wino_maxc_, (size_t)std::max(op.Cin, op.Cout));
             }
         } else if (op.kind == OpKind::DWCONV) {
             d.wt = push(op.weight.data(), op.weight.size());
@@ -173,8 +174,9 @@ void Net::reserve(int max_batch) {
         conv_workspace_init(partial_.as<float>());
     }
     if (wino_elems_) {
-        wino_v_.ensure(wino_elems_ * (size_t)cap_ * sizeof(float));
-        wino_m_.ensure(wino_elems_ * (size_t)cap_ * sizeof(float));
+        const size_t pad = 36 * 256 * wino_maxc_;                // every frequency plane is padded to whole 256-row tiles
+        wino_v_.ensure((wino_elems_ * (size_t)cap_ + pad) * sizeof(float));
+        wino_m_.ensure((wino_elems_ * (size_t)cap_ + pad) * sizeof(float));
     }
     // the 4th input lane and alignment gaps must never hold NaNs
     FH_HIP(hipMemset(arena_.p, 0, arena_.bytes));

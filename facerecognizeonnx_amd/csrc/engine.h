@@ -64,6 +64,7 @@ class Net {
     Plan plan_;
     std::vector<DevOp> dev_;
     DevBuf params_, arena_, partial_, wino_v_, wino_m_;
+    size_t wino_maxc_ = 0;
     size_t wino_elems_ = 0;                                   // per image: 36 * tiles * max(Cin, Cout) of the largest Winograd op
     int cap_ = 0;
     bool stem_ok_ = false;

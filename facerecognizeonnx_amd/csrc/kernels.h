@@ -64,10 +64,11 @@ struct ConvArgs {
     int oact[3];
     int sk_enable;          // allow the stream-K remainder wave
     int cus;                // CUs this launch can occupy (0 = the whole device); sizes the stream-K remainder round
-    // grouped GEMM (Winograd: 36 independent [M x K] x [K x N] products in one launch): `groups` > 1, group g reads
-    // in + g*in_gs, wt + g*wt_gs and writes out1 + g*out_gs (strides in floats); tpg = tiles per group (filled in)
-    int groups, tpg;
-    long in_gs, wt_gs, out_gs;
+    // grouped GEMM (Winograd: 36 independent [rows x K] x [K x N] products stacked along M in one launch): rows
+    // [g*wt_group_rows, (g+1)*wt_group_rows) use the weight matrix wt + g*wt_gs (floats).  wt_group_rows = 0: off;
+    // otherwise a multiple of the tile height (128 covers every configuration but the 256-row one).
+    int wt_group_rows;
+    long wt_gs;
     double t_flops, t_bytes; // algorithmic work of this launch (only used by the optional KernelTimer)
     // filled in by launch_conv: #plain tiles, K-chunk units dealt to helpers, units per helper, #helpers, #remainder
     // tiles, chunks each owner computes itself (0 = no owners: fix-up kernel), slab slots per remainder tile
@@ -86,7 +87,8 @@ void launch_dwpw(const ConvArgs& a, hipStream_t s);
 // in_scale / in_shift (optional): per-input-channel affine applied to in-image pixels by the input transform
 void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, const float* in_scale, const float* in_shift,
                           hipStream_t s);
-void wino_filter_transform(const double g[9], double u[36]);     // host: G g G^T of one 3x3 filter
+void wino_filter_transform(const double g[9], double u[36]);
+long wino_rows(long tiles);                  // rows per frequency plane of the V / M workspaces (tiles rounded up to 256)     // host: G g G^T of one 3x3 filter
 int conv_wt_rows(int Cout);                   // packed weight rows (Cout rounded up to 128)
 size_t conv_slab_floats();
 // host: plan-layout weights [Cout][ks*ks][Cin] -> packed [conv_wt_rows(Cout)][conv_kpad(ks*ks*Cin)] (dst pre-zeroed)

@@ -44,7 +44,7 @@ __device__ __forceinline__ void wino_at(const v4f (&m)[6], v4f (&y)[4]) {
 // aff_s / aff_t (optional): per-channel affine applied to the in-image pixels only — the block's pre-conv BatchNorm, so that the
 // producer need not write a normalised copy of its output (zero padding stays exactly zero).
 __global__ __launch_bounds__(256, 2) void wino_input_kernel(const float* __restrict__ in, float* __restrict__ V, int B, int H, int W,
-                                                            int C, int TY, int TX, const float* __restrict__ aff_s,
+                                                            int C, int TY, int TX, long NTp, const float* __restrict__ aff_s,
                                                             const float* __restrict__ aff_t) {
     const int C4 = C >> 2;
     const long NT = (long)B * TY * TX;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void wino_input_kernel(const float* __restr
             for (int i = 0; i < 6; ++i) t[i][c] = tc[i];
         }
         float* dst = V + (size_t)tile * C + c4 * 4;
-        const size_t fs = (size_t)NT * C;                    // stride between frequency planes
+        const size_t fs = (size_t)NTp * C;                   // stride between frequency planes (rows padded to whole GEMM tiles)
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             v4f o[6];
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void wino_input_kernel(const float* __restr
 struct WinoOutArgs {
     const float* M; const float* bias; const float* slope; const float* res; float* out1; float* out2; const float* s2; const float* t2;
     int B, H, W, C, TY, TX, act;
+    long NTp;
 };
 
 // M [36][NT][C] -> out [B,H,W,C] (H x W = output grid = input grid), epilogue as conv_mfma.hip's
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void wino_output_kernel(const WinoOutArgs p
     const int C = p.C, C4 = C >> 2;
     const long NT = (long)p.B * p.TY * p.TX;
     const long total = NT * C4;
-    const size_t fs = (size_t)NT * C;
+    const size_t fs = (size_t)p.NTp * C;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int c4 = (int)(idx % C4);
         const long tile = idx / C4;
@@ -144,6 +145,8 @@ __global__ __launch_bounds__(256, 2) void wino_output_kernel(const WinoOutArgs p
     }
 }
 
+long wino_rows(long tiles) { return (tiles + 255) / 256 * 256; }   // rows of one frequency plane: whole tiles of every GEMM configuration
+
 static inline int wino_grid(long n) {
     const long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : b > 256 * 16 ? 256 * 16 : b);
@@ -167,23 +170,24 @@ void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float*
     const int TY = (a.H + 3) / 4, TX = (a.W + 3) / 4;
     const long NT = (long)a.B * TY * TX;
     if (NT <= 0) return;
+    const long NTp = wino_rows(NT);                          // rows per frequency plane, padded to whole GEMM tiles
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
-    hipLaunchKernelGGL(wino_input_kernel, dim3(wino_grid(NT * (a.Cin >> 2))), dim3(256), 0, s, a.in, V, a.B, a.H, a.W, a.Cin, TY, TX, in_scale,
+    hipLaunchKernelGGL(wino_input_kernel, dim3(wino_grid(NT * (a.Cin >> 2))), dim3(256), 0, s, a.in, V, a.B, a.H, a.W, a.Cin, TY, TX, NTp, in_scale,
                        in_shift);
     timer.end(s, 8, 0.0, 0.0);
     ConvArgs g{};
     g.in = V; g.wt = wt36; g.out1 = M; g.slabs = a.slabs; g.sk_enable = a.sk_enable; g.cus = a.cus;
-    g.B = (int)NT; g.H = g.W = g.Ho = g.Wo = 1; g.Cin = a.Cin; g.Cout = a.Cout; g.ks = 1; g.stride = 1; g.pad = 0; g.Kpad = a.Cin;
+    g.B = (int)(36 * NTp); g.H = g.W = g.Ho = g.Wo = 1; g.Cin = a.Cin; g.Cout = a.Cout; g.ks = 1; g.stride = 1; g.pad = 0; g.Kpad = a.Cin;
     g.act = (int)Act::NONE; g.res_mode = (int)ResMode::NONE;
-    g.groups = 36; g.in_gs = NT * a.Cin; g.wt_gs = (long)conv_wt_rows(a.Cout) * a.Cin; g.out_gs = NT * a.Cout;
-    // booked on the GEMM: the FLOPs it EXECUTES (physical matrix-core utilisation) and, in the bytes slot of the timer, the
-    // direct-form FLOPs of the convolution it stands for (the algorithmic figure bench.py quotes beside it)
+    g.wt_group_rows = (int)NTp; g.wt_gs = (long)conv_wt_rows(a.Cout) * a.Cin;
+    // booked on the GEMM: the FLOPs it EXECUTES on real rows (physical matrix-core utilisation) and, in the bytes slot of the
+    // timer, the direct-form FLOPs of the convolution it stands for (the algorithmic figure bench.py quotes beside it)
     g.t_flops = 2.0 * 36.0 * (double)NT * a.Cin * a.Cout; g.t_bytes = a.t_flops;
     launch_conv(g, cfg, s);
     WinoOutArgs o{};
     o.M = M; o.bias = a.bias; o.slope = a.slope; o.res = a.res; o.out1 = a.out1; o.out2 = a.out2; o.s2 = a.s2; o.t2 = a.t2;
-    o.B = a.B; o.H = a.H; o.W = a.W; o.C = a.Cout; o.TY = TY; o.TX = TX; o.act = a.act;
+    o.B = a.B; o.H = a.H; o.W = a.W; o.C = a.Cout; o.TY = TY; o.TX = TX; o.act = a.act; o.NTp = NTp;
     timer.begin(s);
     hipLaunchKernelGGL(wino_output_kernel, dim3(wino_grid(NT * (a.Cout >> 2))), dim3(256), 0, s, o);
     timer.end(s, 8, 0.0, 0.0);
