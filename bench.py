@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 CFG_NAMES = ["conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<256,64,4,1>", "conv_igemm_kernel<128,32,4,1>",
              "conv_igemm_kernel<64,64,2,2>", "dwpw_kernel + dwconv3x3 kernels", "other graph ops (incl. stem_conv_u8)", "conv_fixup_kernel",
-             "conv_igemm_kernel<128,32,4,1> grouped (Winograd GEMM)", "wino_input_kernel + wino_output_kernel"]
+             "wino_gemm_kernel<64, 3>", "wino_input_kernel + wino_output_kernel"]
 NTAGS = len(CFG_NAMES)
 
 
@@ -348,8 +348,11 @@ def main():
                                    "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                                    "launches": int(dom[2]), "avg_launch_us": 1e3 * dom[0] / dom[2],
                                    "algorithmic_gflop_per_launch": dom[1] / dom[2] / 1e9,
-                                   "flops_counted": "executed by the matrix cores (a Winograd GEMM is booked with its own 36-group "
-                                                    "product, not with the 4x larger direct-form count of the layer)",
+                                   "flops_counted": "executed by the matrix cores (wino_gemm_kernel = the 36 GEMMs of a Winograd F(4x4,3x3) layer, "
+                                                    "booked with its own product, not with the 4x larger direct-form count of the layer)",
+                                   # the same launches priced with the direct-form (2*MAC) FLOPs of the layers they compute
+                                   "direct_form_achieved": (by[7] if dom[3] == 7 else dom[1]) / (dom[0] * 1e-3) / 1e12,
+                                   "direct_form_frac": (by[7] if dom[3] == 7 else dom[1]) / (dom[0] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                    "all_conv_igemm": {"achieved": allfl / (allms * 1e-3) / 1e12,
                                                       "frac": allfl / (allms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
                                                       "ms_per_step": allms / isteps,

@@ -22,6 +22,7 @@
 namespace fh {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 // B^T (6x6) applied to a 6-vector
 __device__ __forceinline__ void wino_bt(const v4f (&d)[6], v4f (&t)[6]) {
@@ -145,6 +146,85 @@ __global__ __launch_bounds__(256, 2) void wino_output_kernel(const WinoOutArgs p
     }
 }
 
+// ---- the 36 GEMMs: M[f] = V[f] (rows x K) * U[f] (K x N), frequency planes stacked along the rows --------------------------
+// Same tile anatomy as conv_igemm_kernel (LDS-DMA with source-side swizzle, [row][32 k] LDS images, one ds_read_b128 per 4 MFMAs,
+// weights as the MFMA A operand) but nothing else: rows are contiguous, K and N are multiples of 32, the row count a multiple of
+// 256, the epilogue a plain store.  The generic kernel spends ~650 VALU + ~490 SALU instructions per wave on tap / padding / index
+// bookkeeping around the 128 MFMAs of such a short-K tile (rocprofv3: matrix pipe busy 58 %); this one does not.
+__device__ __forceinline__ void wino_dma16(const float* src, v4f* dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+#else
+    (void)src; (void)dst;
+#endif
+}
+
+template <int BN, int OCC>
+__global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M,
+                                                            const int K, const int N, const int rows_per_group, const long wt_gs,
+                                                            const int tiles_n, const int chunks) {
+    constexpr int BM = 128, TN = BN / 32, AL = BM / 32, BL = BN / 32;
+    __shared__ v4f lds[2][(BM + BN) * 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh2 = lane >> 5, fsw = (fr >> 1) & 7;
+    // XCD-contiguous tile order (blockIdx % 8 = XCD): the tiles_n workgroups that read the same rows share an L2
+    const int nb = gridDim.x, q = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+    const int tile = x * q + min(x, r8) + (blockIdx.x >> 3);
+    const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const float* Ug = U + (size_t)(m0 / rows_per_group) * wt_gs;
+
+    const int lrow = tid >> 3;
+    const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);              // source k-column of this lane (swizzle on the source side)
+    const float* a_src = V + (size_t)(m0 + lrow) * K + lqs * 4;
+    const float* b_src = Ug + (size_t)(n0 + lrow) * K + lqs * 4;
+    const size_t row32 = (size_t)32 * K;
+    v4f* const dstA = &lds[0][wid * 64];
+    v4f* const dstB = &lds[0][BM * 8 + wid * 64];
+    auto load_chunk = [&](int buf) {
+        v4f* const dA = dstA + buf * ((BM + BN) * 8);
+        v4f* const dB = dstB + buf * ((BM + BN) * 8);
+#pragma unroll
+        for (int i = 0; i < AL; ++i) wino_dma16(a_src + i * row32, dA + i * 32 * 8);
+#pragma unroll
+        for (int i = 0; i < BL; ++i) wino_dma16(b_src + i * row32, dB + i * 32 * 8);
+        a_src += 32; b_src += 32;
+    };
+    v16f acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    load_chunk(0);
+    __syncthreads();
+    for (int kc = 0; kc < chunks; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < chunks) load_chunk(buf ^ 1);
+        const v4f* X = lds[buf] + (wid * 32 + fr) * 8;
+        const v4f* Wt = lds[buf] + BM * 8 + fr * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = (2 * s + fh2) ^ fsw;
+            const v4f xv = X[col];
+            v4f w[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) w[j] = Wt[j * 32 * 8 + col];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j][e], xv[e], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* orow = M + (size_t)(m0 + wid * 32 + fr) * N + n0 + 4 * fh2;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<v4f*>(orow + j * 32 + 8 * g) = v4f{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+}
+
 long wino_rows(long tiles) { return (tiles + 255) / 256 * 256; }   // rows of one frequency plane: whole tiles of every GEMM configuration
 
 static inline int wino_grid(long n) {
@@ -184,7 +264,22 @@ void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float*
     // booked on the GEMM: the FLOPs it EXECUTES on real rows (physical matrix-core utilisation) and, in the bytes slot of the
     // timer, the direct-form FLOPs of the convolution it stands for (the algorithmic figure bench.py quotes beside it)
     g.t_flops = 2.0 * 36.0 * (double)NT * a.Cin * a.Cout; g.t_bytes = a.t_flops;
-    launch_conv(g, cfg, s);
+    if (a.Cout % 32 == 0 && cfg == 2) {
+        // the lean kernel: 128 x 64 tiles (IResNet-50 at B = 128 / 256: 9.89 / 19.5 ms; 128 x 32: 9.96 / 19.8; 128 x 128: 10.2 / 19.6)
+        const long rows = 36 * NTp;
+        const int chunks = a.Cin / 32;
+        const bool wide = a.Cout % 64 == 0;
+        timer.begin(s);
+        if (wide)
+            hipLaunchKernelGGL((wino_gemm_kernel<64, 3>), dim3((unsigned)((rows / 128) * (a.Cout / 64))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
+                               (int)NTp, g.wt_gs, a.Cout / 64, chunks);
+        else
+            hipLaunchKernelGGL((wino_gemm_kernel<32, 4>), dim3((unsigned)((rows / 128) * (a.Cout / 32))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
+                               (int)NTp, g.wt_gs, a.Cout / 32, chunks);
+        timer.end(s, 7, g.t_flops, g.t_bytes);
+    } else {
+        launch_conv(g, cfg, s);                              // generic grouped instantiation of conv_igemm_kernel
+    }
     WinoOutArgs o{};
     o.M = M; o.bias = a.bias; o.slope = a.slope; o.res = a.res; o.out1 = a.out1; o.out2 = a.out2; o.s2 = a.s2; o.t2 = a.t2;
     o.B = a.B; o.H = a.H; o.W = a.W; o.C = a.Cout; o.TY = TY; o.TX = TX; o.act = a.act; o.NTp = NTp;
