@@ -170,8 +170,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
     }
 }
 
-// GRP: grouped form (several independent GEMMs in one launch) — a separate instantiation, so that the ungrouped convolutions keep
-// their register allocation (with the group decode compiled in, the 128x128 / 256x64 kernels spilled 328 bytes per lane).
+// GRP: grouped form (several GEMMs stacked along M with one weight matrix each, see ConvArgs::wt_group_rows) — a separate
+// instantiation, so that the ungrouped convolutions keep their register allocation.
 template <int BM, int BN, int WM, int WN, int OCC, bool FAST, bool GRP>
 __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const ConvArgs p, const int tiles_n, const int chunks) {
     using TL = Tile<BM, BN, WM, WN>;

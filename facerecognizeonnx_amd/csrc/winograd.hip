@@ -1,4 +1,4 @@
-// winograd.hip — Winograd F(4x4, 3x3) for the deep 3x3 stride-1 convolutions (Cin >= 256) of IResNet.
+// winograd.hip — Winograd F(4x4, 3x3) for the deep 3x3 stride-1 convolutions (Cin >= 128) of IResNet.
 //
 // What it replaces: the same Conv nodes conv_mfma.hip computes directly (reference: ORT inside session_->Run,
 // src/face_recognizer.cpp:279-283).  Y = A^T [ (G g G^T) (.) (B^T d B) ] A on 4x4 output tiles: 36 multiplies per
@@ -8,7 +8,8 @@
 // and why the switch fh_rec_set_winograd exists).
 //
 //   wino_input_kernel   d (6x6 input patch per tile, zero padded)  ->  V[f][tile][ci] = B^T d B, f = 6*i + j
-//   conv_igemm_kernel   36 independent GEMMs in ONE grouped launch:  M[f] = V[f] (tiles x Cin) * U[f] (Cin x Cout)
+//   wino_gemm_kernel    36 independent GEMMs in ONE launch:  M[f] = V[f] (tiles x Cin) * U[f] (Cin x Cout)
+//                       (conv_igemm_kernel's grouped instantiation when Cout is off the 32 grid)
 //   wino_output_kernel  Y = A^T M A, + bias -> PReLU / ReLU -> (+ residual) -> out, optional second output y*s2+t2
 //
 // U[f] = G g G^T is computed once at load time in fp64 (engine.cpp).  Interpolation points 0, +-1, +-2, inf
