@@ -242,7 +242,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
         for (int i = 0; i < AL; ++i) {
             const int m = m0 + lrow + i * RP;
             a_ptr[i] = p.zeros; a_mask[i] = 0;
-            if (m < M) {
+            if (p.ks == 1 && p.stride == 1) {               // plain GEMM rows (1x1 convs, FC, gallery): no pixel arithmetic at all
+                if (m < M) { a_ptr[i] = p.in + (long)m * p.Cin + lqs * 4; a_mask[i] = 1u; }
+            } else if (m < M) {
                 const int n = m / HoWo, rem = m - n * HoWo;
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
