@@ -52,7 +52,26 @@ const OnnxTensor& init_of(const OnnxModel& m, const std::string& name) {
     return it->second;
 }
 
-void bn_scale_shift(const OnnxModel& m, const OnnxNode& bn, std::vector<double>& s, std::vector<double>& t) {
+// Per-channel scale / shift of a BatchNormalization node — or of an element-wise Mul / Add / Sub / Div whose other operand is a
+// constant (a scalar or one value per channel: the Scale layers of SCRFD's regression branches, mean / std normalisation nodes
+// some exporters leave in the graph).  `channels` > 0 broadcasts a scalar constant.
+void bn_scale_shift(const OnnxModel& m, const OnnxNode& bn, std::vector<double>& s, std::vector<double>& t, int channels = 0) {
+    if (bn.op != "BatchNormalization") {
+        const bool c_first = m.inits.count(bn.inputs.at(0)) != 0;
+        const auto& c = init_of(m, bn.inputs.at(c_first ? 0 : 1)).f;
+        if (c.empty()) fail(bn.op + " with an empty constant");
+        if (c_first && (bn.op == "Sub" || bn.op == "Div")) fail(bn.op + " of a constant by a tensor is not supported");
+        const size_t nc = c.size() == 1 && channels > 0 ? (size_t)channels : c.size();
+        s.assign(nc, 1.0); t.assign(nc, 0.0);
+        for (size_t i = 0; i < nc; ++i) {
+            const double v = c[c.size() == 1 ? 0 : i];
+            if (bn.op == "Mul") s[i] = v;
+            else if (bn.op == "Div") s[i] = 1.0 / v;
+            else if (bn.op == "Add") t[i] = v;
+            else t[i] = -v;                                    // Sub
+        }
+        return;
+    }
     const auto& g = init_of(m, bn.inputs[1]).f;
     const auto& be = init_of(m, bn.inputs[2]).f;
     const auto& mu = init_of(m, bn.inputs[3]).f;
@@ -236,9 +255,13 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
         } else if (n.op == "BatchNormalization" || n.op == "Relu" || n.op == "Sigmoid" || n.op == "Flatten" ||
                    n.op == "Transpose" || n.op == "Reshape" || n.op == "PRelu" || n.op == "Resize" || n.op == "Upsample") {
             x.in = {n.inputs[0]};
+        } else if ((n.op == "Mul" || n.op == "Add" || n.op == "Sub" || n.op == "Div") && n.inputs.size() == 2 &&
+                   (m.inits.count(n.inputs[0]) != 0) != (m.inits.count(n.inputs[1]) != 0)) {
+            // tensor (op) constant: a per-channel affine — handled exactly like a BatchNormalization from here on
+            x.op = "BatchNormalization";
+            x.in = {m.inits.count(n.inputs[0]) ? n.inputs[1] : n.inputs[0]};
         } else if (n.op == "Add") {
             x.in = {n.inputs.at(0), n.inputs.at(1)};
-            if (m.inits.count(x.in[0]) || m.inits.count(x.in[1])) fail("Add with a constant operand is not supported");
         } else {
             fail("unsupported operator '" + n.op + "'");
         }
@@ -278,7 +301,7 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
         if (!is_convlike(p) || p->out != bn.in[0] || consumers(p->out) != 1) continue;
         if (p->act != Act::NONE || !p->res.empty() || !p->out2.empty()) continue;
         std::vector<double> s, t;
-        bn_scale_shift(m, *bn.src, s, t);
+        bn_scale_shift(m, *bn.src, s, t, p->Cout);
         if ((int)s.size() != p->Cout) fail("BN channel mismatch after " + p->op);
         size_t per = p->w.size() / (size_t)p->Cout;
         for (int co = 0; co < p->Cout; ++co) {
@@ -332,7 +355,7 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
         GNode* p = producer(bn.in[0]);
         if (!p || p->op != "Conv" || p->group != 1 || p->out != bn.in[0] || !p->out2.empty()) continue;
         std::vector<double> s, t;
-        bn_scale_shift(m, *bn.src, s, t);
+        bn_scale_shift(m, *bn.src, s, t, p->Cout);
         if ((int)s.size() != p->Cout) fail("BN channel mismatch (second output)");
         p->s2.assign(s.begin(), s.end());
         p->t2.assign(t.begin(), t.end());
@@ -479,7 +502,7 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
             const Val vi = it->second;
             const PTensor ti = P.tensors[vi.tensor];
             std::vector<double> s, t;
-            bn_scale_shift(m, *n->src, s, t);
+            bn_scale_shift(m, *n->src, s, t, vi.kind == Val::FLAT_STORAGE ? vi.cols : (vi.tensor == P.input ? 3 : ti.C));
             POp op; op.kind = OpKind::AFFINE; op.name = n->out; op.in = vi.tensor;
             op.H = op.Ho = ti.H; op.W = op.Wo = ti.W; op.Cin = op.Cout = ti.C;
             if (vi.kind == Val::NCHW4D) {

@@ -124,6 +124,10 @@ def run_graph(g: onnx_min.Graph, feeds: dict) -> dict:
             y = _ew("orc_relu", i[0])
         elif n.op == "Sigmoid":
             y = _ew("orc_sigmoid", i[0])
+        elif n.op in ("Mul", "Sub", "Div") or (n.op == "Add" and np.shape(i[0]) != np.shape(i[1])):
+            # element-wise op against a constant (scalar / per-channel, numpy broadcasting), evaluated literally in fp32 as ORT does
+            f = {"Mul": np.multiply, "Sub": np.subtract, "Div": np.divide, "Add": np.add}[n.op]
+            y = f(np.asarray(i[0], np.float32), np.asarray(i[1], np.float32), dtype=np.float32)
         elif n.op == "Add":
             x0 = np.ascontiguousarray(i[0], np.float32); x1 = np.ascontiguousarray(i[1], np.float32)
             assert x0.shape == x1.shape

@@ -173,6 +173,24 @@ def test_winograd_switch_changes_only_rounding():
     assert (1.0 - (e1 * e0).sum(1)).max() < 1e-6                            # embeddings: cosine
 
 
+def test_constant_affine_ops_fold_and_match_oracle(tmp_path):
+    """Mul / Add / Sub / Div against constants (scalar and per-channel) are folded into the neighbouring convolutions."""
+    from tests.test_host_cpu import _affine_graph
+    H, W = 24, 20
+    path = _affine_graph(str(tmp_path / "affine.onnx"), H, W)
+    det = fa.FaceDetector(); odet = oracle.OracleDetector()
+    assert det.loadModel(path) and odet.loadModel(path)
+    frames = util.frames_u8(2, H, W, seed=8)
+    d = dev(frames)
+    assert fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), 2, H, W, W * 3, H * W * 3, 0) == 2
+    torch.cuda.synchronize()
+    got = _det_outputs(det, 2)[0]
+    for i in range(2):
+        inp, _ = oracle.det_preprocess(frames[i], W, H)
+        ref = odet.run_network(inp)[0]
+        np.testing.assert_allclose(got[i], ref.reshape(got[i].shape), rtol=1e-5, atol=2e-5)
+
+
 def test_det_preprocess_bit_exact(models_dir):
     det = fa.FaceDetector()
     assert det.loadModel(util.tiny_scrfd(models_dir, hw=128))

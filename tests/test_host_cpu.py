@@ -168,3 +168,42 @@ def test_sharded_gallery_topk_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def _affine_graph(path, H=24, W=20, C=12, Cout=8):
+    """conv -> Mul(scalar) -> Add(per-channel) -> Relu -> conv -> Sub(scalar) -> Div(per-channel): the element-wise
+    constant ops exporters leave in graphs (SCRFD's Scale layers, normalisation nodes)."""
+    from facerecognizeonnx_amd.synth.onnx_writer import OnnxBuilder
+    rng = np.random.default_rng(5)
+    b = OnnxBuilder("affine")
+    x = b.add_input("input", [1, 3, H, W])
+    def conv(x, cout, cin, k):
+        return b.node("Conv", [x, b.init(b.uid("w"), (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)),
+                               b.init(b.uid("b"), (rng.standard_normal(cout) / 10).astype(np.float32))],
+                      kernel_shape=[k, k], pads=[k // 2] * 4, strides=[1, 1])
+    y = conv(x, C, 3, 3)
+    y = b.node("Mul", [y, b.init("scale0", np.array(1.7, np.float32))])
+    y = b.node("Add", [b.init("shift0", rng.standard_normal((1, C, 1, 1)).astype(np.float32)), y])       # constant first
+    y = b.node("Relu", [y])
+    y = conv(y, Cout, C, 1)
+    y = b.node("Sub", [y, b.init("mean1", np.array([0.25], np.float32))])
+    y = b.node("Div", [y, b.init("std1", rng.uniform(0.5, 2.0, (Cout, 1, 1)).astype(np.float32))])
+    y = b.node("Transpose", [y], perm=[0, 2, 3, 1])
+    b.node("Reshape", [y, b.init("shape", np.array([-1, Cout], np.int64))], outputs=["out"])
+    b.add_output("out", ["A", Cout])
+    return b.save(path)
+
+
+def test_planner_folds_constant_mul_add_sub_div(tmp_path):
+    import facerecognizeonnx_amd as fa
+    from oracle import oracle
+    from tests import torch_ref
+    path = _affine_graph(str(tmp_path / "affine.onnx"))
+    desc = fa.plan_describe(path, 24, 20)
+    assert desc.splitlines()[0].split("ops ")[1].startswith("2 ")          # everything folded into the two convolutions
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((1, 3, 24, 20)).astype(np.float32)
+    od = oracle.OracleDetector(); assert od.loadModel(path)
+    o = od.run_network(x[0])[0]
+    t = np.asarray(torch_ref.run_graph(path, {"input": x})["out"])
+    np.testing.assert_allclose(o, t.reshape(o.shape), rtol=1e-5, atol=1e-5)  # the oracle's literal evaluation vs fp64
