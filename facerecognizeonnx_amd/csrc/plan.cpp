@@ -95,7 +95,45 @@ struct Val {
 
 }  // namespace
 
-Plan build_plan(const OnnxModel& m, int inH, int inW) {
+// Identity and (inference-mode) Dropout nodes on tensors are pass-throughs: drop them, renaming their outputs to their inputs in
+// every later node and in the graph outputs.  Only the node list is copied (the initializers are shared by reference).
+static bool strip_passthrough(const OnnxModel& m, std::vector<OnnxNode>& nodes, std::vector<OnnxValueInfo>& outputs) {
+    bool any = false;
+    for (const auto& n : m.nodes) any = any || ((n.op == "Identity" || n.op == "Dropout") && !n.inputs.empty() && !m.inits.count(n.inputs[0]));
+    if (!any) return false;
+    std::map<std::string, std::string> alias;
+    auto A = [&](const std::string& v) { auto it = alias.find(v); return it == alias.end() ? v : it->second; };
+    for (const auto& n : m.nodes) {
+        if ((n.op == "Identity" || n.op == "Dropout") && !n.inputs.empty() && !m.inits.count(n.inputs[0]) && !n.outputs.empty()) {
+            alias[n.outputs[0]] = A(n.inputs[0]);           // (a Dropout's optional mask output is never used at inference)
+            continue;
+        }
+        OnnxNode c = n;
+        for (auto& i : c.inputs) i = A(i);
+        nodes.push_back(std::move(c));
+    }
+    outputs = m.outputs;
+    for (auto& o : outputs) o.name = A(o.name);
+    return true;
+}
+
+static Plan build_plan_impl(const OnnxModel& m, int inH, int inW);
+
+Plan build_plan(const OnnxModel& m0, int inH, int inW) {
+    std::vector<OnnxNode> nodes;
+    std::vector<OnnxValueInfo> outputs;
+    if (!strip_passthrough(m0, nodes, outputs)) return build_plan_impl(m0, inH, inW);
+    OnnxModel m;                                             // same graph without the pass-through nodes
+    m.nodes = std::move(nodes);
+    m.outputs = std::move(outputs);
+    m.inputs = m0.inputs;
+    m.inits = m0.inits;                                      // (copy: only taken for graphs that contain such nodes)
+    Plan P = build_plan_impl(m, inH, inW);
+    for (size_t i = 0; i < P.outputs.size() && i < m0.outputs.size(); ++i) P.outputs[i].name = m0.outputs[i].name;   // keep the file's output names
+    return P;
+}
+
+static Plan build_plan_impl(const OnnxModel& m, int inH, int inW) {
     if (m.inputs.size() != 1) fail("expected exactly one graph input");
     // ---------------------------------------------------------------- 0. shape / constant pre-pass
     // Exports with dynamic axes (the public det_500m.onnx has H and W dynamic) compute Resize sizes and
@@ -224,7 +262,6 @@ Plan build_plan(const OnnxModel& m, int inH, int inW) {
         if (n.outputs.empty()) fail("node without output");
         x.out = n.outputs[0];
         if (shape_nodes.count(x.out)) { --ord; continue; }   // folded into a constant by the pre-pass
-        if (n.op == "Identity") fail("Identity on a tensor is not supported");
         if (n.op == "Conv") {
             const auto& w = init_of(m, n.inputs.at(1));
             if (w.dims.size() != 4 || w.dims[2] != w.dims[3]) fail("Conv weight must be [Cout,Cin/g,k,k]");

@@ -124,6 +124,8 @@ def run_graph(g: onnx_min.Graph, feeds: dict) -> dict:
             y = _ew("orc_relu", i[0])
         elif n.op == "Sigmoid":
             y = _ew("orc_sigmoid", i[0])
+        elif n.op in ("Identity", "Dropout"):                   # inference: pass-through
+            y = i[0]
         elif n.op in ("Mul", "Sub", "Div") or (n.op == "Add" and np.shape(i[0]) != np.shape(i[1])):
             # element-wise op against a constant (scalar / per-channel, numpy broadcasting), evaluated literally in fp32 as ORT does
             f = {"Mul": np.multiply, "Sub": np.subtract, "Div": np.divide, "Add": np.add}[n.op]

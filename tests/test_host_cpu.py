@@ -171,8 +171,8 @@ def test_sharded_gallery_topk_gloo_world2(tmp_path):
 
 
 def _affine_graph(path, H=24, W=20, C=12, Cout=8):
-    """conv -> Mul(scalar) -> Add(per-channel) -> Relu -> conv -> Sub(scalar) -> Div(per-channel): the element-wise
-    constant ops exporters leave in graphs (SCRFD's Scale layers, normalisation nodes)."""
+    """conv -> Mul(scalar) -> Add(per-channel) -> Relu -> Dropout -> conv -> Identity -> Sub(scalar) -> Div(per-channel): the
+    element-wise constant ops and pass-through nodes exporters leave in graphs (SCRFD's Scale layers, normalisation nodes)."""
     from facerecognizeonnx_amd.synth.onnx_writer import OnnxBuilder
     rng = np.random.default_rng(5)
     b = OnnxBuilder("affine")
@@ -185,7 +185,9 @@ def _affine_graph(path, H=24, W=20, C=12, Cout=8):
     y = b.node("Mul", [y, b.init("scale0", np.array(1.7, np.float32))])
     y = b.node("Add", [b.init("shift0", rng.standard_normal((1, C, 1, 1)).astype(np.float32)), y])       # constant first
     y = b.node("Relu", [y])
+    y = b.node("Dropout", [y], ratio=0.4)                                                               # inference: pass-through
     y = conv(y, Cout, C, 1)
+    y = b.node("Identity", [y])
     y = b.node("Sub", [y, b.init("mean1", np.array([0.25], np.float32))])
     y = b.node("Div", [y, b.init("std1", rng.uniform(0.5, 2.0, (Cout, 1, 1)).astype(np.float32))])
     y = b.node("Transpose", [y], perm=[0, 2, 3, 1])

@@ -35,6 +35,8 @@ def run_graph(path_or_graph, feeds: dict, dtype=torch.float64) -> dict:
             y = torch.sigmoid(i[0])
         elif n.op == "Add":
             y = i[0] + i[1]
+        elif n.op in ("Identity", "Dropout"):                   # inference: pass-through
+            y = i[0]
         elif n.op in ("Mul", "Sub", "Div"):                     # element-wise, numpy-style broadcasting (constant operands)
             y = {"Mul": torch.mul, "Sub": torch.sub, "Div": torch.div}[n.op](i[0], i[1])
         elif n.op == "Shape":
