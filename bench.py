@@ -61,9 +61,18 @@ def parse():
                     "durations then include time-sharing with the other network's kernels, which blurs the roofline attribution")
     ap.add_argument("--from-host", action="store_true", help="secondary measurement: frames start in pinned HOST memory and are "
                     "uploaded over PCIe, double-buffered on a side stream (the PCIe-inclusive rate; never the headline value)")
+    ap.add_argument("--recogniser", default="r50", choices=["r50", "mbf"], help="r50 = w600k_r50 (the reference's model, headline); "
+                    "mbf = w600k_mbf (MobileFaceNet, the buffalo_s / buffalo_sc recogniser): a secondary measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo only to rehearse the N>1 code path")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
+
+
+def rec_model(args):
+    from facerecognizeonnx_amd.synth import models
+    if args.recogniser == "mbf":
+        return models.cached("w600k_mbf_seed300.onnx", models.make_w600k_mbf)
+    return models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
 
 
 def cpu_baseline(det_path, rec_path, frames_np, args):
@@ -127,11 +136,11 @@ def main():
     # synthetic models (seeded; the genuine .onnx files are not available offline)
     if local == 0:
         det_path = models.cached("det_500m_seed100.onnx", models.make_det_500m)
-        rec_path = models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
+        rec_path = rec_model(args)
     if dist is not None:
         dist.barrier()
     det_path = models.cached("det_500m_seed100.onnx", models.make_det_500m)
-    rec_path = models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
+    rec_path = rec_model(args)
     det, rec = fa.FaceDetector(), fa.FaceRecognizer()
     if not det.loadModel(det_path) or not rec.loadModel(rec_path):
         raise SystemExit("model load failed: " + fa._lib.last_error())
@@ -320,7 +329,8 @@ def main():
                                     "detect": f"C3: {B} frames 640x640 per GPU, SCRFD det_500m + decode + NMS"}[args.workload],
                        "frames_per_gpu": B, "faces_per_frame": F, "faces_per_step_rank0": per_step_faces,
                        "score_thr": args.score_thr, "nms_thr": args.nms_thr,
-                       "weights": "synthetic seeded (det seed 100, rec seed 200)",
+                       "weights": "synthetic seeded (det seed 100, rec seed 200)" if args.recogniser == "r50" else
+                                  "synthetic seeded (det seed 100), recogniser = MobileFaceNet w600k_mbf (seed 300) instead of the reference's w600k_r50",
                        "pipelining": "serial, one stream" if (not args.overlap or args.from_host or args.gallery or args.workload != "e2e") else
                                      "detector of batch k+1 on its own HIP stream beside the recogniser of batch k (<= 3 batches in flight)",
                        "input_residency": "pinned host memory, double-buffered H2D over PCIe (PCIe-inclusive)" if args.from_host

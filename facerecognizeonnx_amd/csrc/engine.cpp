@@ -126,7 +126,7 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
                 wino_elems_ = std::max(wino_elems_, 36 * tiles * (size_t)std::max(op.Cin, op.Cout));
                 wino_maxc_ = std::max(wino_maxc_, (size_t)std::max(op.Cin, op.Cout));
             }
-        } else if (op.kind == OpKind::DWCONV) {
+        } else if (op.kind == OpKind::DWCONV || op.kind == OpKind::DWGLOBAL || op.kind == OpKind::GCONV) {
             d.wt = push(op.weight.data(), op.weight.size());
         }
         if (!op.bias.empty()) d.bias = push(op.bias.data(), op.bias.size());
@@ -277,7 +277,16 @@ void Net::run(int batch, hipStream_t s, int first_op) {
             }
             case OpKind::DWCONV:
                 launch_dwconv3x3(tensor_ptr(op.in), P + d.wt, P + d.bias, tensor_ptr(op.out), batch, op.H, op.W, op.Cin, op.stride,
-                                 (int)op.act, s);
+                                 (int)op.act, d.has_slope ? P + d.slope : nullptr, s);
+                tag = 4;
+                break;
+            case OpKind::DWGLOBAL:
+                launch_dwglobal(tensor_ptr(op.in), P + d.wt, P + d.bias, tensor_ptr(op.out), batch, op.ks * op.ks, op.Cin, (int)op.act,
+                                d.has_slope ? P + d.slope : nullptr, s);
+                break;
+            case OpKind::GCONV:
+                launch_gconv3x3(tensor_ptr(op.in), P + d.wt, P + d.bias, tensor_ptr(op.out), batch, op.H, op.W, op.Cin,
+                                (int)(op.weight_group), op.stride, (int)op.act, d.has_slope ? P + d.slope : nullptr, s);
                 tag = 4;
                 break;
             case OpKind::AFFINE:

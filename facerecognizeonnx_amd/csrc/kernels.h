@@ -98,8 +98,15 @@ inline int conv_kpad(int Ktot) { return (Ktot + 31) / 32 * 32; }
 // --------------------------------------------------------------------------------------------
 // Bandwidth-bound graph ops (ops_misc.hip)
 // --------------------------------------------------------------------------------------------
+// depthwise 3x3 pad 1 (+bias, ReLU / PReLU with per-channel slope); w9c = [9][C]
 void launch_dwconv3x3(const float* in, const float* w9c, const float* bias, float* out, int B, int H, int W,
-                      int C, int stride, int act, hipStream_t s);
+                      int C, int stride, int act, const float* slope, hipStream_t s);
+// depthwise k x k VALID over a k x k map -> [B, C] (taps = k*k, w = [taps][C])
+void launch_dwglobal(const float* in, const float* w, const float* bias, float* out, int B, int taps, int C, int act, const float* slope,
+                     hipStream_t s);
+// grouped 3x3 pad 1 with G = 2 | 4 channels per group on both sides; w = [9][C][G]
+void launch_gconv3x3(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, int C, int G, int stride, int act,
+                     const float* slope, hipStream_t s);
 void launch_affine(const float* in, const float* sc, const float* sh, float* out, long pixels, int C, hipStream_t s);
 void launch_act(const float* in, const float* slope, float* out, long pixels, int C, int act, hipStream_t s);
 void launch_add(const float* a, const float* b, float* out, long n, hipStream_t s);

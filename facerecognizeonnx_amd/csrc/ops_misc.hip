@@ -33,7 +33,8 @@ __device__ __forceinline__ float act1(float v, int act, float slope) {
 template <int STRIDE, int STRIP>
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        int B, int H, int W, int C, int Ho, int Wo, int act) {
+                                                        int B, int H, int W, int C, int Ho, int Wo, int act,
+                                                        const float* __restrict__ slope) {
     constexpr int ROWS = (STRIP - 1) * STRIDE + 3;
     const int C4 = C >> 2;
     const int strips = (Ho + STRIP - 1) / STRIP;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 #pragma unroll
         for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const v4f*>(w + t * C + c4 * 4);
         const v4f b4 = *reinterpret_cast<const v4f*>(bias + c4 * 4);
+        const v4f sl4 = slope ? *reinterpret_cast<const v4f*>(slope + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f};
         v4f acc[STRIP];
 #pragma unroll
         for (int o = 0; o < STRIP; ++o) acc[o] = b4;
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
             if (oy >= Ho) break;
             v4f v = acc[o];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act1(v[e], act, 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = act1(v[e], act, sl4[e]);
             *reinterpret_cast<v4f*>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4) = v;
         }
     }
@@ -86,7 +88,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 template <int STRIDE, int STRIP>
 __global__ __launch_bounds__(256) void dwconv3x3_hstrip_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
-                                                        int B, int H, int W, int C, int Ho, int Wo, int act) {
+                                                        int B, int H, int W, int C, int Ho, int Wo, int act,
+                                                        const float* __restrict__ slope) {
     constexpr int COLS = (STRIP - 1) * STRIDE + 3;
     const int C4 = C >> 2;
     const int strips = (Wo + STRIP - 1) / STRIP;
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_hstrip_kernel(const float* __re
 #pragma unroll
         for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const v4f*>(w + t * C + c4 * 4);
         const v4f b4 = *reinterpret_cast<const v4f*>(bias + c4 * 4);
+        const v4f sl4 = slope ? *reinterpret_cast<const v4f*>(slope + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f};
         v4f acc[STRIP];
 #pragma unroll
         for (int o = 0; o < STRIP; ++o) acc[o] = b4;
@@ -128,23 +132,94 @@ __global__ __launch_bounds__(256) void dwconv3x3_hstrip_kernel(const float* __re
             if (ox >= Wo) break;
             v4f v = acc[o];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act1(v[e], act, 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = act1(v[e], act, sl4[e]);
             *reinterpret_cast<v4f*>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4) = v;
         }
     }
 }
 
 void launch_dwconv3x3(const float* in, const float* w9c, const float* bias, float* out, int B, int H, int W, int C,
-                      int stride, int act, hipStream_t s) {
+                      int stride, int act, const float* slope, hipStream_t s) {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     constexpr int STRIP = 4;
     if (stride == 1) {
         const long total = (long)B * ((Ho + STRIP - 1) / STRIP) * Wo * (C / 4);
-        hipLaunchKernelGGL((dwconv3x3_kernel<1, STRIP>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo, act);
+        hipLaunchKernelGGL((dwconv3x3_kernel<1, STRIP>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo, act, slope);
     } else {
         const long total = (long)B * Ho * ((Wo + STRIP - 1) / STRIP) * (C / 4);
-        hipLaunchKernelGGL((dwconv3x3_hstrip_kernel<2, STRIP>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo, act);
+        hipLaunchKernelGGL((dwconv3x3_hstrip_kernel<2, STRIP>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo, act, slope);
     }
+}
+
+// Depthwise k x k VALID convolution over a k x k map -> one value per channel (MobileFaceNet's "GDC" layer):
+// out[b][c] = bias[c] + sum_p w[p][c] * in[b][p][c].  Thread = 4 channels of one image; lanes walk the channels.
+__global__ __launch_bounds__(256) void dwglobal_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int B, int taps, int C, int act, const float* __restrict__ slope) {
+    const int C4 = C >> 2;
+    const long total = (long)B * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        const long b = idx / C4;
+        v4f acc = *reinterpret_cast<const v4f*>(bias + c4 * 4);
+        const float* x = in + (size_t)b * taps * C + c4 * 4;
+        for (int p = 0; p < taps; ++p) acc += *reinterpret_cast<const v4f*>(x + (size_t)p * C) * *reinterpret_cast<const v4f*>(w + (size_t)p * C + c4 * 4);
+        const v4f sl4 = slope ? *reinterpret_cast<const v4f*>(slope + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = act1(acc[e], act, sl4[e]);
+        *reinterpret_cast<v4f*>(out + (size_t)b * C + c4 * 4) = acc;
+    }
+}
+void launch_dwglobal(const float* in, const float* w, const float* bias, float* out, int B, int taps, int C, int act, const float* slope,
+                     hipStream_t s) {
+    const long total = (long)B * (C / 4);
+    if (total > 0) hipLaunchKernelGGL(dwglobal_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, w, bias, out, B, taps, C, act, slope);
+}
+
+// Grouped 3x3 convolution (pad 1, stride 1 | 2) with G = 2 or 4 channels per group on both sides (MobileFaceNet's second layer:
+// 64 groups of 2).  A float4 of 4 consecutive output channels depends on exactly the same 4 input channels, so the kernel has the
+// shape of the depthwise one with a G-wide dot product per tap.  w: [9][C][G].  Thread = 4 channels of one output pixel.
+template <int G>
+__global__ __launch_bounds__(256) void gconv3x3_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ out, int B, int H, int W, int C, int Ho, int Wo, int stride, int act,
+                                                       const float* __restrict__ slope) {
+    const int C4 = C >> 2;
+    const long total = (long)B * Ho * Wo * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % C4);
+        long r = idx / C4;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        v4f acc = *reinterpret_cast<const v4f*>(bias + c4 * 4);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * stride - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * stride - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const v4f x = *reinterpret_cast<const v4f*>(in + (((size_t)n * H + iy) * W + ix) * C + c4 * 4);
+                const float* wt = w + ((size_t)(ky * 3 + kx) * C + c4 * 4) * G;      // [4 output channels][G]
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < G; ++j) acc[e] += wt[e * G + j] * x[(e / G) * G + j];
+            }
+        }
+        const v4f sl4 = slope ? *reinterpret_cast<const v4f*>(slope + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = act1(acc[e], act, sl4[e]);
+        *reinterpret_cast<v4f*>(out + (((size_t)n * Ho + oy) * Wo + ox) * C + c4 * 4) = acc;
+    }
+}
+void launch_gconv3x3(const float* in, const float* w, const float* bias, float* out, int B, int H, int W, int C, int G, int stride, int act,
+                     const float* slope, hipStream_t s) {
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+    const long total = (long)B * Ho * Wo * (C / 4);
+    if (total <= 0) return;
+    if (G == 2) hipLaunchKernelGGL(gconv3x3_kernel<2>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w, bias, out, B, H, W, C, Ho, Wo, stride, act, slope);
+    else hipLaunchKernelGGL(gconv3x3_kernel<4>, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w, bias, out, B, H, W, C, Ho, Wo, stride, act, slope);
 }
 
 // generic per-channel pass, scalar channel indexing (C need not be a multiple of 4)

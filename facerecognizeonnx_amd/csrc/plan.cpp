@@ -274,10 +274,24 @@ static Plan build_plan_impl(const OnnxModel& m, int inH, int inW) {
             for (auto p : pd) if (p != x.pad) fail("asymmetric padding");
             for (auto d : dl) if (d != 1) fail("dilation != 1");
             if (n.attr_s("auto_pad", "NOTSET") != "NOTSET") fail("auto_pad not supported");
-            if (!((x.ks == 3 && x.pad == 1) || (x.ks == 1 && x.pad == 0))) fail("only 3x3/p1 and 1x1/p0 convolutions are supported");
+            // dense: 3x3/p1 and 1x1/p0; grouped: additionally k x k VALID (checked against the input size when the op is emitted)
+            if (!((x.ks == 3 && x.pad == 1) || (x.ks == 1 && x.pad == 0) || (x.group > 1 && x.pad == 0)))
+                fail("only 3x3/p1 and 1x1/p0 convolutions are supported");
             x.w.assign(w.f.begin(), w.f.end());
             if (n.inputs.size() > 2 && !n.inputs[2].empty()) { const auto& b = init_of(m, n.inputs[2]).f; x.b.assign(b.begin(), b.end()); }
             else x.b.assign((size_t)x.Cout, 0.0);
+            x.in = {n.inputs[0]};
+        } else if (n.op == "MatMul") {
+            // [rows, K] x constant [K, N]: a bias-less Linear (torch exports nn.Linear(bias=False) this way) -> Gemm with W^T
+            const auto& w = init_of(m, n.inputs.at(1));
+            if (w.dims.size() != 2) fail("MatMul: the second operand must be a 2-D initializer");
+            const int K = (int)w.dims[0], N = (int)w.dims[1];
+            x.op = "Gemm";
+            x.Cout = N; x.CinG = K;
+            x.w.resize((size_t)N * K);
+            for (int k = 0; k < K; ++k)
+                for (int j = 0; j < N; ++j) x.w[(size_t)j * K + k] = w.f[(size_t)k * N + j];
+            x.b.assign((size_t)N, 0.0);
             x.in = {n.inputs[0]};
         } else if (n.op == "Gemm") {
             const auto& w = init_of(m, n.inputs.at(1));
@@ -479,15 +493,44 @@ static Plan build_plan_impl(const OnnxModel& m, int inH, int inW) {
                                 (float)n->w[((size_t)co * logicalCin + ci) * taps + t];
                 op.macs = (double)op.Ho * op.Wo * n->Cout * taps * logicalCin;
             } else {
-                if (!(n->group == logicalCin && n->CinG == 1 && n->Cout == logicalCin && n->ks == 3))
-                    fail("grouped Conv other than depthwise 3x3 is not supported");
-                if (ti.C % 4) fail("depthwise Conv needs C % 4 == 0");
-                if (!n->res.empty() || !n->out2.empty()) fail("internal: fused residual on depthwise");
-                op.kind = OpKind::DWCONV;
-                op.weight.assign((size_t)9 * ti.C, 0.f);
-                for (int c = 0; c < ti.C; ++c)
-                    for (int t = 0; t < 9; ++t) op.weight[(size_t)t * ti.C + c] = (float)n->w[(size_t)c * 9 + t];
-                op.macs = (double)op.Ho * op.Wo * ti.C * 9;
+                const bool depthwise = n->group == logicalCin && n->CinG == 1 && n->Cout == logicalCin;
+                const int coutG = n->Cout / n->group;
+                if (ti.C % 4 || n->Cout % 4) fail("grouped Conv needs C % 4 == 0");
+                if (!n->res.empty() || !n->out2.empty()) fail("internal: fused residual on a grouped conv");
+                if (depthwise && n->ks == 3 && n->pad == 1) {
+                    op.kind = OpKind::DWCONV;
+                    op.weight.assign((size_t)9 * ti.C, 0.f);
+                    for (int c = 0; c < ti.C; ++c)
+                        for (int t = 0; t < 9; ++t) op.weight[(size_t)t * ti.C + c] = (float)n->w[(size_t)c * 9 + t];
+                    op.macs = (double)op.Ho * op.Wo * ti.C * 9;
+                } else if (depthwise && n->pad == 0 && n->stride == 1 && n->ks == ti.H && n->ks == ti.W) {
+                    op.kind = OpKind::DWGLOBAL;                  // k x k VALID over a k x k map -> 1 x 1
+                    op.weight.assign((size_t)taps * ti.C, 0.f);
+                    for (int c = 0; c < ti.C; ++c)
+                        for (int t = 0; t < taps; ++t) op.weight[(size_t)t * ti.C + c] = (float)n->w[(size_t)c * taps + t];
+                    op.macs = (double)ti.C * taps;
+                } else if (n->ks == 3 && n->pad == 1 && n->CinG == coutG && (coutG == 2 || coutG == 4) && n->Cout == logicalCin) {
+                    op.kind = OpKind::GCONV;                     // weight [9][Cout][G]: tap-major, then output channel, then its G inputs
+                    const int G = coutG;
+                    op.weight_group = G;
+                    op.weight.assign((size_t)9 * n->Cout * G, 0.f);
+                    for (int co = 0; co < n->Cout; ++co)
+                        for (int j = 0; j < G; ++j)
+                            for (int t = 0; t < 9; ++t)
+                                op.weight[((size_t)t * n->Cout + co) * G + j] = (float)n->w[((size_t)co * G + j) * 9 + t];
+                    op.macs = (double)op.Ho * op.Wo * n->Cout * 9 * G;
+                } else if ((n->ks == 3 && n->pad == 1) || (n->ks == 1 && n->pad == 0)) {
+                    // any other grouping: a dense convolution with block-diagonal weights (correct, not fast)
+                    op.kind = OpKind::CONV;
+                    op.weight.assign((size_t)n->Cout * taps * ti.C, 0.f);
+                    for (int co = 0; co < n->Cout; ++co)
+                        for (int j = 0; j < n->CinG; ++j)
+                            for (int t = 0; t < taps; ++t)
+                                op.weight[((size_t)co * taps + t) * ti.C + (co / coutG) * n->CinG + j] = (float)n->w[((size_t)co * n->CinG + j) * taps + t];
+                    op.macs = (double)op.Ho * op.Wo * n->Cout * taps * n->CinG;
+                } else {
+                    fail("unsupported grouped Conv geometry at " + n->out);
+                }
             }
             if (op.kind == OpKind::CONV && ti.C % 4) fail("Conv needs stored Cin % 4 == 0 at " + n->out);
             if (n->write_out1) {
@@ -772,7 +815,7 @@ static Plan build_plan_impl(const OnnxModel& m, int inH, int inW) {
 }
 
 std::string Plan::describe() const {
-    static const char* kinds[] = {"CONV", "DWCONV", "GEMM", "AFFINE", "ACT", "ADD", "UPSAMPLE", "DW+PW"};
+    static const char* kinds[] = {"CONV", "DWCONV", "GEMM", "AFFINE", "ACT", "ADD", "UPSAMPLE", "DW+PW", "DWGLOBAL", "GCONV"};
     static const char* acts[] = {"", "+relu", "+prelu", "+sigmoid"};
     std::ostringstream os;
     os << "input " << inH << "x" << inW << "  ops " << ops.size() << "  tensors " << tensors.size()

@@ -14,7 +14,9 @@ namespace fh {
 
 enum class Act : int { NONE = 0, RELU = 1, PRELU = 2, SIGMOID = 3 };
 enum class ResMode : int { NONE = 0, SAME = 1, UP2X = 2 };
-enum class OpKind : int { CONV = 0, DWCONV = 1, GEMM = 2, AFFINE = 3, ACT = 4, ADD = 5, UPSAMPLE = 6, DWPW = 7 };
+// DWGLOBAL: depthwise k x k VALID convolution over a k x k map (MobileFaceNet's GDC) -> 1 x 1; weight [k*k][C].
+// GCONV: grouped 3x3 with 2 or 4 channels per group on both sides (MobileFaceNet's second layer); weight [9][Cout][G].
+enum class OpKind : int { CONV = 0, DWCONV = 1, GEMM = 2, AFFINE = 3, ACT = 4, ADD = 5, UPSAMPLE = 6, DWPW = 7, DWGLOBAL = 8, GCONV = 9 };
 
 struct PTensor {
     std::string name;
@@ -49,6 +51,7 @@ struct POp {
     std::vector<float> dw_weight, dw_bias;
     Act dw_act = Act::NONE;
     int dw_stride = 1;
+    int weight_group = 1;            // GCONV: channels per group (2 | 4)
     double macs = 0;                  // multiply-accumulates per image
     double bytes = 0;                 // algorithmic activation bytes per image (in + res + outs)
 };

@@ -131,6 +131,79 @@ def make_iresnet(path: str, layers: Sequence[int] = (3, 4, 14, 3),
     return b.save(path)
 
 
+def make_mobilefacenet(path: str, blocks: Sequence[int] = (1, 4, 6, 2), base: int = 128, size: int = 112, feat: int = 512,
+                       seed: int = 300, fold_bn: bool = True, batch_dim="N") -> str:
+    """MobileFaceNet as arcface_torch builds it (``mbf``, scale 2 -> base = 128 channels): the ``w600k_mbf`` recogniser of
+    buffalo_s / buffalo_sc ("keep the graph executor generic so w600k_mbf also loads").
+
+    stem 3x3 s2 -> a GROUPED 3x3 (base/2 groups of 2 channels) -> three stages of [DepthWise s2, Residual x n]
+    (DepthWise = 1x1 expand + PReLU, depthwise 3x3 + PReLU, 1x1 linear project) -> 1x1 conv_sep to 4*base channels
+    -> GDC: depthwise k x k VALID conv over the whole map (k = size/16), Flatten, bias-less Linear (a MatMul node), BN.
+    Op set: Conv (dense, grouped, depthwise 3x3, depthwise global), BatchNormalization, PRelu, Add, Flatten, MatMul.
+    """
+    W = _W(seed)
+    b = OnnxBuilder("mobilefacenet")
+    x = b.add_input("input.1", [batch_dim, 3, size, size])
+
+    def conv_bn(x, cin, cout, k, stride, pad, groups, tag, gain=2.0):
+        w = W.conv(cout, cin // groups, k, gain)
+        bn = W.bn(cout)
+        kw = dict(kernel_shape=[k, k], strides=[stride, stride], pads=[pad] * 4, dilations=[1, 1], group=groups)
+        if fold_bn:
+            w2, b2 = _fold(w, None, bn)
+            return b.node("Conv", [x, b.init(f"{tag}.weight", w2), b.init(f"{tag}.bias", b2)], **kw)
+        y = b.node("Conv", [x, b.init(f"{tag}.weight", w)], **kw)
+        g, beta, m, v = bn
+        n = [b.init(f"{tag}.bn.weight", g), b.init(f"{tag}.bn.bias", beta), b.init(f"{tag}.bn.running_mean", m),
+             b.init(f"{tag}.bn.running_var", v)]
+        return b.node("BatchNormalization", [y] + n, epsilon=float(_BN_EPS), momentum=0.9)
+
+    def conv_block(x, cin, cout, k, stride, pad, groups, tag):          # Conv + BN + PReLU
+        y = conv_bn(x, cin, cout, k, stride, pad, groups, tag)
+        return b.node("PRelu", [y, b.init(f"{tag}.prelu", W.slope(cout).reshape(cout, 1, 1))])
+
+    def depth_wise(x, cin, cout, stride, groups, residual, tag):
+        y = conv_block(x, cin, groups, 1, 1, 0, 1, f"{tag}.conv")
+        y = conv_block(y, groups, groups, 3, stride, 1, groups, f"{tag}.conv_dw")
+        y = conv_bn(y, groups, cout, 1, 1, 0, 1, f"{tag}.project", gain=0.5 if residual else 1.0)
+        return b.node("Add", [x, y]) if residual else y
+
+    c1, c2 = base, 2 * base
+    x = conv_block(x, 3, c1, 3, 2, 1, 1, "layers.0")
+    if blocks[0] == 1:
+        x = conv_block(x, c1, c1, 3, 1, 1, c1 // 2, "layers.1")         # groups = 64 at scale 2: two channels per group
+    else:
+        for i in range(blocks[0]):
+            x = depth_wise(x, c1, c1, 1, c1, True, f"layers.1.{i}")
+    x = depth_wise(x, c1, c1, 2, c1, False, "layers.2")
+    for i in range(blocks[1]):
+        x = depth_wise(x, c1, c1, 1, c1, True, f"layers.3.{i}")
+    x = depth_wise(x, c1, c2, 2, 2 * c1, False, "layers.4")
+    for i in range(blocks[2]):
+        x = depth_wise(x, c2, c2, 1, 2 * c1, True, f"layers.5.{i}")
+    x = depth_wise(x, c2, c2, 2, 4 * c1, False, "layers.6")
+    for i in range(blocks[3]):
+        x = depth_wise(x, c2, c2, 1, 2 * c1, True, f"layers.7.{i}")
+    cs = 4 * base
+    x = conv_block(x, c2, cs, 1, 1, 0, 1, "conv_sep")
+    k = size // 16
+    x = conv_bn(x, cs, cs, k, 1, 0, cs, "features.gdc", gain=1.0)       # global depthwise conv: [N, cs, 1, 1]
+    x = b.node("Flatten", [x], axis=1)
+    wfc = (W.rng.standard_normal((cs, feat)) * np.sqrt(1.0 / cs)).astype(np.float32)      # MatMul: [K, N]
+    x = b.node("MatMul", [x, b.init("features.linear.weight_t", wfc)])
+    g, beta, m, v = W.bn(feat)
+    n = [b.init("features.bn.weight", g), b.init("features.bn.bias", beta), b.init("features.bn.running_mean", m),
+         b.init("features.bn.running_var", v)]
+    out = b.node("BatchNormalization", [x] + n, outputs=["516"], epsilon=float(_BN_EPS), momentum=0.9)
+    b.add_output(out, [batch_dim, feat])
+    return b.save(path)
+
+
+def make_w600k_mbf(path: str, seed: int = 300) -> str:
+    """The buffalo_s / buffalo_sc recogniser: MobileFaceNet, blocks (1, 4, 6, 2), scale 2, 112x112 -> 512-d."""
+    return make_mobilefacenet(path, seed=seed)
+
+
 def make_w600k_r50(path: str, seed: int = 200) -> str:
     """Full-size IResNet-50 (43.6 M params, 6.31 GMAC/face)."""
     return make_iresnet(path, (3, 4, 14, 3), (64, 128, 256, 512), 112, 512, seed)

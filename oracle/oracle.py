@@ -173,6 +173,11 @@ def run_graph(g: onnx_min.Graph, feeds: dict) -> dict:
             y = i[0].reshape([int(d) for d in i[1]])
         elif n.op == "Flatten":
             y = i[0].reshape(i[0].shape[0], -1)
+        elif n.op == "MatMul":                                  # [M,K] x constant [K,N] (a bias-less Linear)
+            x0 = np.ascontiguousarray(i[0], np.float32)
+            wt = np.ascontiguousarray(np.asarray(i[1], np.float32).T)
+            y = np.empty((x0.shape[0], wt.shape[0]), np.float32)
+            L.orc_gemm_nt(_f(x0), x0.shape[0], x0.shape[1], _f(wt), None, wt.shape[0], _f(y))
         elif n.op == "Gemm":
             assert a.get("transB", 0) == 1 and a.get("alpha", 1.0) == 1.0 and a.get("beta", 1.0) == 1.0
             x0 = np.ascontiguousarray(i[0], np.float32)

@@ -9,4 +9,6 @@ run f4 --faces-per-frame 4
 run c4_gallery --gallery 1000000 --frames 64
 run from_host --from-host
 run overlap --overlap
+run mbf_embed --workload embed --recogniser mbf
+run mbf_e2e --recogniser mbf
 ls $O

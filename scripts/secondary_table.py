@@ -8,7 +8,9 @@ rows = [("headline", "headline: 128 frames 640x640, detect+align+embed, F=1", "(
         ("f4", "headline with 4 faces per frame", "`--faces-per-frame 4`"),
         ("c4_gallery", "C4: 64 frames end-to-end + top-16 of a 1 M x 512 gallery", "`--gallery 1000000 --frames 64`"),
         ("from_host", "PCIe-inclusive headline (pinned host frames, double-buffered H2D)", "`--from-host`"),
-        ("overlap", "headline, streaming form: detector of batch k+1 on its own stream beside the recogniser of batch k", "`--overlap`")]
+        ("overlap", "headline, streaming form: detector of batch k+1 on its own stream beside the recogniser of batch k", "`--overlap`"),
+        ("mbf_embed", "MobileFaceNet (w600k_mbf, the buffalo_sc recogniser) instead of w600k_r50: 256 pre-aligned crops", "`--workload embed --recogniser mbf`"),
+        ("mbf_e2e", "headline pipeline with MobileFaceNet as the recogniser", "`--recogniser mbf`")]
 out = [f"# Round {tag} — other BASELINE.json configurations (same build as profiles/{tag}_summary.md)", "",
        "`python bench.py --steps 10 --warmup 3 --no-cpu-baseline <args>` on one MI355X, HBM-resident inputs unless stated, fp32.", "",
        "| config | args | value | ms / step | dominant kernel (achieved, frac of its roofline) | all conv launches |", "|---|---|---|---|---|---|"]

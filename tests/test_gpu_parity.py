@@ -408,6 +408,46 @@ def test_tiny_iresnet_embeddings(models_dir, fold_bn):
         assert abs(np.linalg.norm(got[i]) - 1.0) < 1e-5
 
 
+@pytest.mark.parametrize("fold_bn", [True, False])
+def test_tiny_mobilefacenet_embeddings(models_dir, fold_bn):
+    """w600k_mbf's op set: grouped 3x3 (2 channels per group), depthwise 3x3 + PReLU, 1x1 expand / project with
+    residual, global depthwise conv (GDC), bias-less Linear exported as MatMul, BatchNorm1d."""
+    path = util.tiny_mbf(models_dir, fold_bn=fold_bn)
+    desc = fa.plan_describe(path, 112, 112)
+    assert "GCONV" in desc and "DWGLOBAL" in desc and "DWCONV" in desc and "+prelu" in desc
+    rec = fa.FaceRecognizer(); orec = oracle.OracleRecognizer()
+    assert rec.loadModel(path) and orec.loadModel(path)
+    assert rec.feature_dim() == 128
+    n = 5
+    crops = util.frames_u8(n, 112, 112, seed=4)
+    cd = dev(crops)
+    out = torch.zeros((n, 128), device="cuda"); raw = torch.zeros((n, 128), device="cuda")
+    assert rec.embed_aligned_dev(cd.data_ptr(), n, out.data_ptr(), raw.data_ptr()) == n
+    torch.cuda.synchronize()
+    got, graw = out.cpu().numpy(), raw.cpu().numpy()
+    for i in range(n):
+        inp = oracle.rec_preprocess(crops[i])
+        r = oracle.run_graph(orec.g, {orec.g.inputs[0][0]: inp[None]})[orec.g.outputs[0][0]].reshape(-1)
+        np.testing.assert_allclose(graw[i], r, rtol=1e-4, atol=1e-4)
+        assert 1.0 - float(np.dot(got[i], oracle.l2_normalize(r))) < 1e-5
+
+
+def test_full_size_mobilefacenet_cosine():
+    from facerecognizeonnx_amd.synth import models
+    path = models.cached("w600k_mbf_seed300.onnx", models.make_w600k_mbf)
+    rec = fa.FaceRecognizer(); orec = oracle.OracleRecognizer()
+    assert rec.loadModel(path) and orec.loadModel(path)
+    n = 3
+    crops = util.frames_u8(n, 112, 112, seed=6)
+    out = torch.zeros((n, 512), device="cuda")
+    assert rec.embed_aligned_dev(dev(crops).data_ptr(), n, out.data_ptr()) == n
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for i in range(n):
+        r = oracle.run_graph(orec.g, {orec.g.inputs[0][0]: oracle.rec_preprocess(crops[i])[None]})[orec.g.outputs[0][0]].reshape(-1)
+        assert 1.0 - float(np.dot(got[i], oracle.l2_normalize(r))) < 1e-5    # north-star bar is 1e-3
+
+
 def test_extract_feature_host_api(models_dir):
     path = util.tiny_iresnet(models_dir)
     rec = fa.FaceRecognizer(); orec = oracle.OracleRecognizer()

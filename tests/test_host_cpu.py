@@ -209,3 +209,21 @@ def test_planner_folds_constant_mul_add_sub_div(tmp_path):
     o = od.run_network(x[0])[0]
     t = np.asarray(torch_ref.run_graph(path, {"input": x})["out"])
     np.testing.assert_allclose(o, t.reshape(o.shape), rtol=1e-5, atol=1e-5)  # the oracle's literal evaluation vs fp64
+
+
+def test_mobilefacenet_plans_and_oracle_matches_fp64(models_dir):
+    """The buffalo_s / buffalo_sc recogniser (w600k_mbf) loads through the same planner; the oracle evaluates its graph."""
+    import facerecognizeonnx_amd as fa
+    from facerecognizeonnx_amd.synth import models
+    from oracle import oracle
+    from tests import torch_ref, util
+    full = fa.plan_describe(models.cached("w600k_mbf_seed300.onnx", models.make_w600k_mbf), 112, 112)
+    head = full.splitlines()[0]
+    assert "ops 50" in head and 0.40 < float(head.split("GMAC/image ")[1].split()[0]) < 0.47      # MobileFaceNet: ~0.44 GMAC
+    assert "GCONV k3s1 56x56x128 -> 56x56x128+prelu" in full and "DWGLOBAL k7s1 7x7x512 -> 1x1x512" in full
+    path = util.tiny_mbf(models_dir, fold_bn=False)
+    x = np.random.default_rng(3).standard_normal((1, 3, 112, 112)).astype(np.float32)
+    g = oracle.OracleRecognizer(); assert g.loadModel(path)
+    o = oracle.run_graph(g.g, {g.g.inputs[0][0]: x})[g.g.outputs[0][0]]
+    t = np.asarray(torch_ref.run_graph(path, {g.g.inputs[0][0]: x})[g.g.outputs[0][0]])
+    np.testing.assert_allclose(o, t, rtol=1e-4, atol=1e-4)

@@ -56,6 +56,8 @@ def run_graph(path_or_graph, feeds: dict, dtype=torch.float64) -> dict:
             y = i[0].reshape([int(d) for d in i[1]])
         elif n.op == "Flatten":
             y = i[0].flatten(1)
+        elif n.op == "MatMul":
+            y = i[0] @ i[1]
         elif n.op == "Gemm":
             y = F.linear(i[0], i[1], i[2] if len(i) > 2 else None)
         else:

@@ -15,6 +15,12 @@ def tiny_iresnet(d, fold_bn=True, seed=1):
                                112, 512, seed=seed, fold_bn=fold_bn)
 
 
+def tiny_mbf(d, fold_bn=True, seed=3):
+    """MobileFaceNet with 16 base channels: every op kind of the full w600k_mbf graph (grouped 3x3, depthwise + PReLU, GDC, MatMul)."""
+    return models.make_mobilefacenet(os.path.join(d, f"m_tiny_{int(fold_bn)}_{seed}.onnx"), (1, 2, 2, 1), 16, 112, 128, seed=seed,
+                                     fold_bn=fold_bn)
+
+
 def tiny_scrfd(d, hw=None, seed=2, cls_bias=-2.0):
     return models.make_scrfd(os.path.join(d, f"s_tiny_{hw}_{seed}.onnx"), (1, 2, 1, 2), (8, 8, 16, 24, 32, 48), 8, 16,
                              seed=seed, cls_bias=cls_bias, static_hw=hw)
