@@ -295,6 +295,31 @@ def test_detect_host_api_matches_oracle_end_to_end(models_dir):
     assert len(det.detect_records(np.zeros((0, 0, 3), np.uint8))) == 0
 
 
+def test_detect_edge_cases(models_dir):
+    """Large non-square frame (strong down-scale + letterbox), a padded row pitch, truncation to the caller's buffer, a threshold
+    nothing passes, and a 1 x 1 image — the guards and the un-scale / truncation arithmetic of face_detector.cpp:92-137,249-278."""
+    path = util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0)
+    det = fa.FaceDetector(); odet = oracle.OracleDetector()
+    assert det.loadModel(path) and odet.loadModel(path)
+    big = util.frames_u8(1, 1080, 1920, seed=31, smooth=True)[0]                 # scale = 128/1920: boxes are un-scaled by 15x
+    got, ref = det.detect_records(big, 0.5, 0.4), odet.detect(big, 0.5, 0.4)
+    assert len(ref) > 0 and abs(len(got) - len(ref)) <= max(2, len(ref) // 50)
+    m = min(len(got), len(ref), 5)
+    for a, b in zip(got[:m], ref[:m]):
+        assert abs(a["score"] - b["score"]) < 1e-4
+        assert max(abs(int(a[k]) - int(b[k])) for k in ("x", "y", "w", "h")) <= 15       # one network-output ulp x the 15x un-scale
+    # the same pixels behind a padded row pitch (cv::Mat::step > cols * 3) give the same records
+    padded = np.zeros((1080, 1920 * 3 + 64), np.uint8); padded[:, :1920 * 3] = big.reshape(1080, -1)
+    view = np.lib.stride_tricks.as_strided(padded, shape=(1080, 1920, 3), strides=(padded.strides[0], 3, 1))
+    assert det.detect_records(view, 0.5, 0.4).tobytes() == got.tobytes()
+    # truncation: the best max_faces records, in the same (score-descending) order
+    if len(got) > 3:
+        assert det.detect_records(big, 0.5, 0.4, max_faces=3).tobytes() == got[:3].tobytes()
+    assert len(det.detect_records(big, 1.0, 0.4)) == 0 and len(odet.detect(big, 1.0, 0.4)) == 0       # sigmoid scores never exceed 1
+    tiny = np.full((1, 1, 3), 200, np.uint8)
+    assert len(det.detect_records(tiny, 0.5, 0.4)) == len(odet.detect(tiny, 0.5, 0.4))
+
+
 def test_c1_single_jpeg_detect_matches_oracle():
     """BASELINE.json configs[0]: one 640x640 JPEG -> imread -> det_500m detect (full-size synthetic graph)."""
     from facerecognizeonnx_amd.synth import models
