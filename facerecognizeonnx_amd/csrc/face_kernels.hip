@@ -143,10 +143,8 @@ __global__ __launch_bounds__(256) void scrfd_decode_kernel(const DecodeArgs a) {
     const int gw8 = a.inW / 8, gh8 = a.inH / 8, gw16 = a.inW / 16, gh16 = a.inH / 16, gw32 = a.inW / 32, gh32 = a.inH / 32;
     const int n8 = gw8 * gh8 * 2, n16 = gw16 * gh16 * 2, n32 = gw32 * gh32 * 2;
     const int N = n8 + n16 + n32;
-    const long total = (long)a.B * N;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(t / N);
-        const int r = (int)(t - (long)b * N);
+    const int b = blockIdx.y;                              // one grid row per frame: no 64-bit index arithmetic per anchor
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < N; r += gridDim.x * blockDim.x) {
         int si, i, gw, s, ns;
         if (r < n8) { si = 0; i = r; gw = gw8; s = 8; ns = n8; }
         else if (r < n8 + n16) { si = 1; i = r - n8; gw = gw16; s = 16; ns = n16; }
@@ -170,8 +168,9 @@ __global__ __launch_bounds__(256) void scrfd_decode_kernel(const DecodeArgs a) {
 }
 
 void launch_scrfd_decode(const DecodeArgs& a, hipStream_t s) {
-    const long total = (long)a.B * ((a.inW / 8) * (a.inH / 8) + (a.inW / 16) * (a.inH / 16) + (a.inW / 32) * (a.inH / 32)) * 2;
-    hipLaunchKernelGGL(scrfd_decode_kernel, dim3(grid_for(total)), dim3(256), 0, s, a);
+    const int N = ((a.inW / 8) * (a.inH / 8) + (a.inW / 16) * (a.inH / 16) + (a.inW / 32) * (a.inH / 32)) * 2;
+    if (N <= 0 || a.B <= 0) return;
+    hipLaunchKernelGGL(scrfd_decode_kernel, dim3((N + 255) / 256, a.B), dim3(256), 0, s, a);
 }
 
 // The reference's own layout: rows [n, feat >= 15] = x1,y1,x2,y2,score,kps (src/face_detector.cpp:242-325)
@@ -356,6 +355,8 @@ __device__ int estimate_similarity5(const float* from, const float* to, double* 
     return 1;
 }
 
+constexpr int ALIGN_PARTS = 4;
+
 __global__ __launch_bounds__(256) void align_kernel(const uint8_t* __restrict__ frames, long img_stride, int rows, int cols, int step,
                                                     const FaceRec* __restrict__ faces, const int* __restrict__ frame_of, int outH,
                                                     int outW, uint8_t* __restrict__ crops, int* __restrict__ ok,
@@ -363,13 +364,15 @@ __global__ __launch_bounds__(256) void align_kernel(const uint8_t* __restrict__ 
     __shared__ double Ms[6];
     __shared__ int mode;          // 1 warp, 2 crop-resize, 0 empty
     __shared__ int cbox[4];
-    const int n = blockIdx.x, tid = threadIdx.x;
+    // ALIGN_PARTS workgroups per face: each repeats the (serial, fp64) transform estimate and warps its share of the pixels —
+    // with one workgroup per face a 128-face batch left half the CUs idle behind that serial section
+    const int n = blockIdx.x / ALIGN_PARTS, part = blockIdx.x - n * ALIGN_PARTS, tid = threadIdx.x;
     // `live` (device-side face count) lets a pipeline launch a fixed number of slots without a host
     // round trip; slots beyond it produce an empty (all-zero) crop and ok = 0.
     const bool dead = live && n >= live[0];
     const FaceRec face = dead ? FaceRec{} : faces[n];
     const uint8_t* img = frames + (size_t)(dead ? 0 : (frame_of ? frame_of[n] : n)) * img_stride;
-    if (tid == 0 && dead) { mode = 0; ok[n] = 0; }
+    if (tid == 0 && dead) { mode = 0; if (part == 0) ok[n] = 0; }
     if (tid == 0 && !dead) {
         const float tmpl[10] = {38.2946f, 51.6963f, 73.5318f, 51.5014f, 56.0252f, 71.7366f, 41.5493f, 92.3655f, 70.7299f, 92.2041f};
         double M[6];
@@ -389,25 +392,26 @@ __global__ __launch_bounds__(256) void align_kernel(const uint8_t* __restrict__ 
             if (x1 - x0 > 0 && y1 - y0 > 0) { cbox[0] = x0; cbox[1] = y0; cbox[2] = x1 - x0; cbox[3] = y1 - y0; mode = 2; }
             else mode = 0;
         }
-        ok[n] = mode;
+        if (part == 0) ok[n] = mode;
     }
     __syncthreads();
     uint8_t* dst = crops + (size_t)n * outH * outW * 3;
     const int npx = outH * outW;
+    const int px_lo = (int)((long)npx * part / ALIGN_PARTS), px_hi = (int)((long)npx * (part + 1) / ALIGN_PARTS);
     if (mode == 0) {
-        for (int i = tid; i < npx * 3; i += 256) dst[i] = 0;
+        for (int i = px_lo * 3 + tid; i < px_hi * 3; i += 256) dst[i] = 0;
         return;
     }
     if (mode == 2) {
         const uint8_t* s = img + (size_t)cbox[1] * step + cbox[0] * 3;
-        for (int i = tid; i < npx; i += 256) {
+        for (int i = px_lo + tid; i < px_hi; i += 256) {
             const int x = i % outW, y = i / outW;
             for (int c = 0; c < 3; ++c) dst[i * 3 + c] = (uint8_t)resize_px(s, cbox[3], cbox[2], step, outH, outW, x, y, c);
         }
         return;
     }
     const double m0 = Ms[0], m1 = Ms[1], m2 = Ms[2], m3 = Ms[3], m4 = Ms[4], m5 = Ms[5];
-    for (int i = tid; i < npx; i += 256) {
+    for (int i = px_lo + tid; i < px_hi; i += 256) {
         const int x = i % outW, y = i / outW;
         const int X0 = cv_round_d((m1 * y + m2) * 1024) + 16;
         const int Y0 = cv_round_d((m4 * y + m5) * 1024) + 16;
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256) void align_kernel(const uint8_t* __restrict__ 
 void launch_align(const uint8_t* frames, long img_stride, int rows, int cols, int step, const FaceRec* faces, const int* frame_of,
                   int n, int outH, int outW, uint8_t* crops, int* ok, hipStream_t s, const int* live) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(align_kernel, dim3(n), dim3(256), 0, s, frames, img_stride, rows, cols, step, faces, frame_of, outH, outW, crops, ok, live);
+    hipLaunchKernelGGL(align_kernel, dim3(n * ALIGN_PARTS), dim3(256), 0, s, frames, img_stride, rows, cols, step, faces, frame_of, outH, outW, crops, ok, live);
 }
 
 // ------------------------------------------------------------------------------------------
