@@ -17,6 +17,9 @@
 // consecutive lanes walk the channels, so all transfers are whole 128-byte lines.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <stdexcept>
+
 #include "kernels.h"
 #include "plan.h"
 
@@ -49,12 +52,13 @@ __global__ __launch_bounds__(256, 2) void wino_input_kernel(const float* __restr
                                                             int C, int TY, int TX, long NTp, const float* __restrict__ aff_s,
                                                             const float* __restrict__ aff_t) {
     const int C4 = C >> 2;
-    const long NT = (long)B * TY * TX;
-    const long total = NT * C4;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % C4);
-        const long tile = idx / C4;
-        const int tx = (int)(tile % TX), ty = (int)((tile / TX) % TY), b = (int)(tile / ((long)TX * TY));
+    // (32-bit index arithmetic: tiles * C/4 < 2^31 is checked by the launcher; 64-bit div / mod per thread is not free)
+    const int NT = B * TY * TX;
+    const int total = NT * C4;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int c4 = idx % C4;
+        const int tile = idx / C4;
+        const int tx = tile % TX, ty = (tile / TX) % TY, b = tile / (TX * TY);
         const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
         const float* img = in + (size_t)b * H * W * C + c4 * 4;
         v4f as4 = {1.f, 1.f, 1.f, 1.f}, at4 = {0.f, 0.f, 0.f, 0.f};
@@ -96,13 +100,13 @@ struct WinoOutArgs {
 // M [36][NT][C] -> out [B,H,W,C] (H x W = output grid = input grid), epilogue as conv_mfma.hip's
 __global__ __launch_bounds__(256, 2) void wino_output_kernel(const WinoOutArgs p) {
     const int C = p.C, C4 = C >> 2;
-    const long NT = (long)p.B * p.TY * p.TX;
-    const long total = NT * C4;
+    const int NT = p.B * p.TY * p.TX;
+    const int total = NT * C4;
     const size_t fs = (size_t)p.NTp * C;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(idx % C4);
-        const long tile = idx / C4;
-        const int tx = (int)(tile % p.TX), ty = (int)((tile / p.TX) % p.TY), b = (int)(tile / ((long)p.TX * p.TY));
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int c4 = idx % C4;
+        const int tile = idx / C4;
+        const int tx = tile % p.TX, ty = (tile / p.TX) % p.TY, b = tile / (p.TX * p.TY);
         const float* src = p.M + (size_t)tile * C + c4 * 4;
         v4f t[4][6];                                         // t[y][j] = (A^T M)[y][j]
 #pragma unroll
@@ -251,6 +255,8 @@ void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float*
     const int TY = (a.H + 3) / 4, TX = (a.W + 3) / 4;
     const long NT = (long)a.B * TY * TX;
     if (NT <= 0) return;
+    if (NT * (std::max(a.Cin, a.Cout) / 4) >= (1L << 31) || 36 * (NT + 256) >= (1L << 31))
+        throw std::runtime_error("winograd: batch too large for the 32-bit tile index (split the batch)");
     const long NTp = wino_rows(NT);                          // rows per frequency plane, padded to whole GEMM tiles
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
