@@ -370,6 +370,14 @@ def main():
                                    "per_kernel_ms_per_step": {CFG_NAMES[i]: ms[i] / isteps for i in range(NTAGS) if ln[i] > 0},
                                    "measured_on": f"{isteps} instrumented steps run right after the timed region (same inputs); "
                                                   f"instrumented step = {1e3 * instr_dt / isteps:.2f} ms"}
+            if args.workload == "detect" and ln[4] > 0 and "roofline" in out and ms[4] > max(c[0] for c in conv):
+                # SCRFD alone: the fused depthwise blocks take more of the step than any MFMA kernel, and they are bandwidth-bound
+                # (SURVEY.md 8d): price them against HBM with the planner's algorithmic activation bytes (in + out of each fused op)
+                gbs = by[4] / (ms[4] * 1e-3) / 1e9
+                out["roofline"].update({"bound": "hbm", "kernel": CFG_NAMES[4], "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                                        "frac": gbs / 8000.0, "traffic": None, "launches": int(ln[4]), "avg_launch_us": 1e3 * ms[4] / ln[4],
+                                        "algorithmic_gflop_per_launch": None,
+                                        "algorithmic_mbytes_per_launch": by[4] / ln[4] / 1e6})
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(det_path, rec_path, host, args)
         print(json.dumps(out), flush=True)
