@@ -56,6 +56,7 @@ PROTOTYPES = {
     "fh_det_output_dev": (_vp, [_vp, _i, _ip, _ip]),
     "fh_det_input_dev": (_vp, [_vp]),
     "fh_det_postprocess_dev": (_i, [_vp, _i, _f, _f, _vp, _i, _vp, _vp]),
+    "fh_postprocess_rows_dev": (_i, [_vp, _i, _i, _i, _f, _f, _f, _vp, _i, _vp, _vp]),
     "fh_rec_create": (_vp, [C.c_char_p]),
     "fh_rec_destroy": (None, [_vp]),
     "fh_rec_input_size": (_i, [_vp, _ip, _ip]),
@@ -68,6 +69,7 @@ PROTOTYPES = {
     "fh_compare": (_f, [_vp, _i, _vp, _i]),
     "fh_rec_embed_aligned_dev": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "fh_rec_align_dev": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _i, _vp, _vp, _vp]),
+    "fh_rec_input_dev": (_vp, [_vp]),
     "fh_rec_embed_faces_dev": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _i, _vp, _vp, _vp]),
     "fh_pipeline_run_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "fh_pipeline_submit_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

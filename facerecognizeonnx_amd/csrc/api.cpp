@@ -1,4 +1,5 @@
 // api.cpp — the extern "C" boundary declared in include/facehip.h.
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -26,6 +27,9 @@ int guarded(F&& f) {
     }
 }
 int arg_error(const char* msg) { g_err = msg; return FH_ERR_ARG; }
+// bytes a caller's row-strided image (cv::Mat data / step, a numpy column slice, a Mat ROI) really owns: the last row ends after
+// cols*3 bytes, not after a whole pitch
+size_t host_image_bytes(int rows, int cols, int step) { return (size_t)(rows - 1) * step + (size_t)cols * 3; }
 hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 }  // namespace
 
@@ -119,7 +123,7 @@ int fh_det_detect(fh_det* d, const uint8_t* bgr, int rows, int cols, int step, f
         d->img.ensure(bytes);
         d->out.ensure((size_t)max_out * sizeof(fh_face));
         d->cnt.ensure(sizeof(int));
-        FH_HIP(hipMemcpy(d->img.p, bgr, bytes, hipMemcpyHostToDevice));
+        FH_HIP(hipMemcpy(d->img.p, bgr, host_image_bytes(rows, cols, step), hipMemcpyHostToDevice));
         try {
             d->det.detect_dev(d->img.as<uint8_t>(), 1, rows, cols, step, (long)bytes, score_thr, nms_thr, d->out.as<fh::FaceRec>(),
                               max_out, d->cnt.as<int>(), nullptr);
@@ -153,6 +157,35 @@ int fh_det_postprocess_dev(fh_det* d, int n, float score_thr, float nms_thr, fh_
     return guarded([&] { d->det.postprocess_dev(n, score_thr, nms_thr, reinterpret_cast<fh::FaceRec*>(out), max_pf, counts, S(stream)); return n; });
 }
 
+// FaceDetector::postprocess + nms on caller-supplied pre-decoded rows (src/face_detector.cpp:224-338,356-384)
+int fh_postprocess_rows_dev(const float* rows, int n, int rows_per_frame, int feat, float scale, float score_thr, float nms_thr,
+                            fh_face* out, int max_pf, int* counts, void* stream) {
+    if (!rows || !out || !counts) return arg_error("fh_postprocess_rows_dev: null argument");
+    if (n <= 0 || rows_per_frame <= 0 || max_pf <= 0 || !(scale > 0.f)) return arg_error("fh_postprocess_rows_dev: bad size");
+    if ((long)n * rows_per_frame >= (1L << 31) / 16) return arg_error("fh_postprocess_rows_dev: too many rows");
+    return guarded([&] {
+        hipStream_t s = S(stream);
+        if (feat < 15) {                                                   // "Unexpected output shape format" :300-303,326-328 -> no boxes
+            FH_HIP(hipMemsetAsync(counts, 0, (size_t)n * sizeof(int), s));
+            return n;
+        }
+        static fh::DevBuf cand, keys, ws, count;
+        int cap = 1;
+        while (cap < rows_per_frame) cap <<= 1;                           // the in-place bitonic sort needs a power of two
+        cand.ensure((size_t)n * cap * sizeof(fh::FaceRec));
+        keys.ensure((size_t)n * cap * sizeof(unsigned long long));
+        ws.ensure((size_t)n * cap * sizeof(int));
+        count.ensure((size_t)n * sizeof(int));
+        FH_HIP(hipMemsetAsync(count.p, 0, (size_t)n * sizeof(int), s));
+        fh::launch_rows_threshold(rows, n, rows_per_frame, feat, scale, score_thr, cand.as<fh::FaceRec>(), keys.as<unsigned long long>(),
+                                  count.as<int>(), cap, s);
+        fh::launch_sort_nms(cand.as<fh::FaceRec>(), keys.as<unsigned long long>(), count.as<int>(), cap, n, nms_thr,
+                            reinterpret_cast<fh::FaceRec*>(out), counts, max_pf, ws.as<int>(), s);
+        FH_HIP(hipGetLastError());
+        return n;
+    });
+}
+
 // ---------------------------------------------------------------------------------- recognizer
 fh_rec* fh_rec_create(const char* onnx_path) {
     if (!onnx_path) { g_err = "fh_rec_create: null path"; return nullptr; }
@@ -172,9 +205,15 @@ double fh_rec_macs_per_face(const fh_rec* r) { return r ? const_cast<fh_rec*>(r)
 double fh_rec_act_bytes_per_face(const fh_rec* r) { return r ? const_cast<fh_rec*>(r)->rec.net().plan().act_bytes : 0.0; }
 int fh_rec_set_chunk(fh_rec* r, int n) {
     if (!r || n <= 0) return arg_error("fh_rec_set_chunk: bad argument");
+    // the kernels index one pass's tensors with 32-bit element offsets: the largest per-face tensor times the chunk must stay < 2^31
+    size_t biggest = 1;
+    for (const auto& t : r->rec.net().plan().tensors) biggest = std::max(biggest, t.elems());
+    const long limit = (long)(((1UL << 31) - 1) / biggest);
+    if (n > limit) return arg_error("fh_rec_set_chunk: chunk too large for the 32-bit tensor offsets of one pass");
     r->rec.max_chunk = n;
     return FH_OK;
 }
+const float* fh_rec_input_dev(fh_rec* r) { return r && r->rec.net().capacity() > 0 ? r->rec.net().input() : nullptr; }
 
 int fh_rec_embed_aligned_dev(fh_rec* r, const uint8_t* crops, int n, float* out, float* raw, void* stream) {
     if (!r || !crops || !out || n <= 0) return arg_error("fh_rec_embed_aligned_dev: bad argument");
@@ -207,7 +246,7 @@ int fh_rec_extract(fh_rec* r, const uint8_t* bgr, int rows, int cols, int step, 
         r->img.ensure(bytes);
         r->face.ensure(sizeof(fh_face) + sizeof(int));
         r->emb.ensure((size_t)r->rec.dim() * sizeof(float));
-        FH_HIP(hipMemcpy(r->img.p, bgr, bytes, hipMemcpyHostToDevice));
+        FH_HIP(hipMemcpy(r->img.p, bgr, host_image_bytes(rows, cols, step), hipMemcpyHostToDevice));
         FH_HIP(hipMemcpy(r->face.p, face, sizeof(fh_face), hipMemcpyHostToDevice));
         int* okp = reinterpret_cast<int*>(r->face.as<uint8_t>() + sizeof(fh_face));
         r->rec.embed_faces_dev(r->img.as<uint8_t>(), rows, cols, step, (long)bytes, r->face.as<fh::FaceRec>(), nullptr, 1, r->emb.as<float>(), okp, nullptr);
@@ -228,7 +267,7 @@ int fh_rec_extract_simple(fh_rec* r, const uint8_t* bgr, int rows, int cols, int
         const size_t bytes = (size_t)rows * step;
         r->img.ensure(bytes);
         r->emb.ensure((size_t)r->rec.dim() * sizeof(float));
-        FH_HIP(hipMemcpy(r->img.p, bgr, bytes, hipMemcpyHostToDevice));
+        FH_HIP(hipMemcpy(r->img.p, bgr, host_image_bytes(rows, cols, step), hipMemcpyHostToDevice));
         r->rec.resize_embed_dev(r->img.as<uint8_t>(), 1, rows, cols, step, (long)bytes, r->emb.as<float>(), nullptr);
         FH_HIP(hipMemcpy(out, r->emb.p, (size_t)r->rec.dim() * sizeof(float), hipMemcpyDeviceToHost));
         return r->rec.dim();

@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <stdexcept>
 
 #include "kernels.h"
 #include "plan.h"
@@ -601,6 +602,9 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
 void launch_conv(const ConvArgs& a, int cfg, hipStream_t s) {
     const long M = (long)a.B * a.Ho * a.Wo;
     if (M <= 0) return;
+    // the loader and the epilogue index pixels and tensor elements with 32-bit integers
+    if ((long)a.B * a.H * a.W * a.Cin >= (1L << 31) || M * a.Cout >= (1L << 31))
+        throw std::runtime_error("conv: tensor too large for the 32-bit element offsets of one launch (split the batch)");
     if (cfg < 0) cfg = conv_pick_cfg(M, a.Cout);
     switch (cfg) {
         case 0: launch_cfg<128, 128, 2, 2, 2>(a, 2, 0, s); break;

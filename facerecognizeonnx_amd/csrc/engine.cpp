@@ -135,17 +135,11 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
     }
     // A Winograd conv that is the only reader of its producer's BatchNorm'ed second output takes the producer's plain output
     // instead and lets its input transform apply the affine (exact: padding stays zero): the second output is never written.
+    // The planner finds these pairs (POp::bn_src) and keeps the plain output alive up to the consumer.
     for (size_t i = 0; i < plan_.ops.size(); ++i) {
-        if (!dev_[i].wino) continue;
-        const int t = plan_.ops[i].in;
-        int uses = 0, prod = -1;
-        for (size_t j = 0; j < plan_.ops.size(); ++j) {
-            const POp& o = plan_.ops[j];
-            for (int x : {o.in, o.in2, o.res}) if (x == t) ++uses;
-            if (o.out2 == t && o.out >= 0 && (o.kind == OpKind::CONV) && j < i) prod = (int)j;
-        }
-        for (const auto& o : plan_.outputs) if (o.tensor == t) ++uses;
-        if (prod > 0 && uses == 1 && dev_[prod].has_aff) { dev_[i].aff_src = prod; dev_[prod].aff_dst = (int)i; }   // (op 0 = the stem keeps its own path)
+        const int prod = plan_.ops[i].bn_src;
+        if (!dev_[i].wino || prod <= 0 || !dev_[prod].has_aff) continue;        // (op 0 = the stem keeps its own path)
+        dev_[i].aff_src = prod; dev_[prod].aff_dst = (int)i;
     }
     {   // can the first conv take the u8 image directly?  (3x3, Cin = 3 stored as 4, plain epilogue)
         const POp& op = plan_.ops[0];

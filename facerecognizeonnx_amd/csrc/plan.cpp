@@ -771,6 +771,24 @@ static Plan build_plan_impl(const OnnxModel& m, int inH, int inW) {
             pt.last = (int)i;
         }
     }
+    // BatchNorm-in-the-transform links (POp::bn_src): the consumer may read the producer's PLAIN output at its own position,
+    // which the op list above does not show — extend that tensor's lifetime so the arena cannot hand its buffer out in between
+    // (e.g. when a block's shortcut convolution, the plain output's last listed reader, is scheduled before conv1).
+    for (size_t i = 0; i < P.ops.size(); ++i) {
+        POp& c = P.ops[i];
+        if (c.kind != OpKind::CONV || c.ks != 3 || c.stride != 1 || c.pad != 1 || c.in < 0) continue;
+        int uses = 0, prod = -1;
+        for (size_t j = 0; j < P.ops.size(); ++j) {
+            const POp& o = P.ops[j];
+            for (int x : {o.in, o.in2, o.res}) if (x == c.in) ++uses;
+            if (o.out2 == c.in && o.out >= 0 && o.kind == OpKind::CONV && j < i) prod = (int)j;
+        }
+        for (const auto& o : P.outputs) if (o.tensor == c.in) ++uses;
+        if (prod < 0 || uses != 1) continue;
+        c.bn_src = prod;
+        PTensor& plain = P.tensors[P.ops[prod].out];
+        plain.last = std::max(plain.last, (int)i);
+    }
     const int nops = (int)P.ops.size();
     for (auto& t : P.tensors) {
         if (t.is_input) t.first = 0;
@@ -829,9 +847,16 @@ std::string Plan::describe() const {
         if (!o.outs.empty()) os << " [merged x" << o.outs.size() << "]";
         if (o.res >= 0) os << (o.res_mode == ResMode::UP2X ? " +res(up2x)" : " +res");
         if (o.out2 >= 0) os << (o.out >= 0 ? " +bn2nd" : " bn2nd-only");
+        if (o.bn_src >= 0) os << " bn<-op" << o.bn_src;
+        os << "  [in t" << o.in << " out t" << o.out << " out2 t" << o.out2 << "]";
         os << "  MMAC " << o.macs * 1e-6 << "\n";
     }
     for (auto& d : outputs) os << "out " << d.name << " [" << d.rows << "x" << d.cols << "]\n";
+    for (size_t i = 0; i < tensors.size(); ++i) {                  // arena placement (per image, in floats) and lifetime in op indices
+        const PTensor& t = tensors[i];
+        if (t.first < 0) continue;
+        os << "tensor t" << i << " " << t.H << "x" << t.W << "x" << t.C << " off " << t.offset << " live " << t.first << ".." << t.last << "\n";
+    }
     return os.str();
 }
 

@@ -52,6 +52,10 @@ struct POp {
     Act dw_act = Act::NONE;
     int dw_stride = 1;
     int weight_group = 1;            // GCONV: channels per group (2 | 4)
+    // 3x3 stride-1 pad-1 CONV whose input is the BatchNorm'ed second output of op[bn_src] and which is that tensor's only reader:
+    // the engine's Winograd input transform may read op[bn_src].out instead and apply s2 / t2 itself (exact: padding stays
+    // zero), so that the second output is never written.  The planner keeps op[bn_src].out alive up to this op for that.
+    int bn_src = -1;
     double macs = 0;                  // multiply-accumulates per image
     double bytes = 0;                 // algorithmic activation bytes per image (in + res + outs)
 };

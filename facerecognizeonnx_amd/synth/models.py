@@ -62,12 +62,14 @@ def _fold(w, b, bn):
 def make_iresnet(path: str, layers: Sequence[int] = (3, 4, 14, 3),
                  widths: Sequence[int] = (64, 128, 256, 512), size: int = 112,
                  feat: int = 512, seed: int = 200, fold_bn: bool = True,
-                 batch_dim="N") -> str:
+                 batch_dim="N", downsample_first: bool = False) -> str:
     """IResNet as arcface_torch builds it.
 
     fold_bn=True ships Conv(+bias) where a BN follows a conv (as the public file does);
     fold_bn=False keeps every BatchNormalization node so the loader's Conv→BN folding is
     exercised as well.  The pre-conv ``bn1`` of each block and the tail BNs always stay.
+    downsample_first=True writes a block's shortcut convolution in front of its bn1 / conv1 nodes (a legal
+    topological order some exporters produce): the block input then has its last listed reader BEFORE conv1.
     """
     W = _W(seed)
     b = OnnxBuilder("iresnet")
@@ -106,13 +108,16 @@ def make_iresnet(path: str, layers: Sequence[int] = (3, 4, 14, 3),
         for bi in range(nblk):
             stride = 2 if bi == 0 else 1
             tag = f"layer{li + 1}.{bi}"
+            sc = None
+            if bi == 0 and downsample_first:
+                sc = conv_bn(x, cin, planes, 1, stride, f"{tag}.downsample", 1.0)
             y = bn_node(x, cin, f"{tag}.bn1")
             y = conv_bn(y, cin, planes, 3, 1, f"{tag}.conv1", 1.0)
             y = prelu(y, planes, f"{tag}.prelu")
             y = conv_bn(y, planes, planes, 3, stride, f"{tag}.conv2", 0.5)
-            if bi == 0:
+            if bi == 0 and sc is None:
                 sc = conv_bn(x, cin, planes, 1, stride, f"{tag}.downsample", 1.0)
-            else:
+            elif sc is None:
                 sc = x
             x = b.node("Add", [y, sc])
             cin = planes

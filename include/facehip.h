@@ -76,6 +76,13 @@ FH_API const float* fh_det_output_dev(fh_det* d, int index, int* rows, int* cols
 FH_API const float* fh_det_input_dev(fh_det* d);          /* preprocessed input, NHWC with 4 lanes */
 FH_API int fh_det_postprocess_dev(fh_det* d, int n, float score_thr, float nms_thr, fh_face* d_out, int max_per_frame,
                                   int* d_counts, void* stream);
+/* FaceDetector::postprocess + nms (src/face_detector.cpp:224-338,356-384) on caller-supplied pre-decoded rows:
+ * d_rows = [n][rows_per_frame][feat >= 15] fp32 (x1,y1,x2,y2,score,10 kps) in HBM; `scale` is the letterbox scale the
+ * reference divides by.  Same kernels as the detector's own post-processing, without a graph in front: for callers that
+ * decode elsewhere, and the hook through which the parity tests push crafted rows (ties, zero-area boxes, > 2048
+ * survivors) through both branches of the NMS kernel.  Uses one process-wide scratch: calls must not overlap. */
+FH_API int fh_postprocess_rows_dev(const float* d_rows, int n, int rows_per_frame, int feat, float scale, float score_thr,
+                                   float nms_thr, fh_face* d_out, int max_per_frame, int* d_counts, void* stream);
 
 /* ---- FaceRecognizer ----------------------------------------------------------------------
  * fh_rec_create          <- FaceRecognizer ctor + loadModel (src/face_recognizer.cpp:5-13,21-91)
@@ -103,6 +110,8 @@ FH_API int fh_rec_embed_aligned_dev(fh_rec* r, const uint8_t* d_crops, int n, fl
 FH_API int fh_rec_align_dev(fh_rec* r, const uint8_t* d_frames, int rows, int cols, int step, long long frame_stride,
                             const fh_face* d_faces, const int* d_frame_of, int n, uint8_t* d_crops, int* d_ok,
                             void* stream);
+/* preprocessed network input of the last pass (NHWC, 4 lanes; only materialised with fh_rec_set_fused_stem(r, 0)) */
+FH_API const float* fh_rec_input_dev(fh_rec* r);
 FH_API int fh_rec_embed_faces_dev(fh_rec* r, const uint8_t* d_frames, int rows, int cols, int step,
                                   long long frame_stride, const fh_face* d_faces, const int* d_frame_of, int n,
                                   float* d_out, int* d_ok, void* stream);
@@ -155,9 +164,7 @@ FH_API int fh_timing_collect(double* ms, double* flops, double* bytes, long long
 FH_API int fh_timing_collect_ops(double* ms, double* flops, int* tag, int cap);   /* per launch, in order */
 FH_API int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k);
 FH_API int fh_rec_set_conv_cfg(fh_rec* r, int cfg, int stream_k);
-/* on (default): the u8 preprocess is fused into the first convolution and the preprocessed input tensor is
- * never materialised; off: separate preprocess kernel (needed for fh_det_input_dev). */
-/* 3x3 stride-1 convolutions with >= 256 input channels run as Winograd F(4x4,3x3) (a quarter of the matrix-core work,
+/* 3x3 stride-1 convolutions with >= 128 input channels run as Winograd F(4x4,3x3) (a quarter of the matrix-core work,
  * fp32 rounding error ~25x the direct form's: see DESIGN.md) unless switched off here; 0 = direct form everywhere. */
 FH_API int fh_det_set_winograd(fh_det* d, int on);
 FH_API int fh_rec_set_winograd(fh_rec* r, int on);
@@ -166,6 +173,8 @@ FH_API int fh_rec_set_winograd(fh_rec* r, int on);
  * remainder round.  0 = the whole device (default). */
 FH_API int fh_det_set_cus(fh_det* d, int cus);
 FH_API int fh_rec_set_cus(fh_rec* r, int cus);
+/* on (default): the u8 preprocess is fused into the first convolution and the preprocessed input tensor is
+ * never materialised; off: separate preprocess kernel (needed for fh_det_input_dev). */
 FH_API int fh_det_set_fused_stem(fh_det* d, int on);
 FH_API int fh_rec_set_fused_stem(fh_rec* r, int on);
 

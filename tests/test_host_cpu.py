@@ -227,3 +227,29 @@ def test_mobilefacenet_plans_and_oracle_matches_fp64(models_dir):
     o = oracle.run_graph(g.g, {g.g.inputs[0][0]: x})[g.g.outputs[0][0]]
     t = np.asarray(torch_ref.run_graph(path, {g.g.inputs[0][0]: x})[g.g.outputs[0][0]])
     np.testing.assert_allclose(o, t, rtol=1e-4, atol=1e-4)
+
+
+def test_planner_keeps_plain_output_alive_for_the_winograd_bn_link(tmp_path):
+    """A Winograd conv1 may read its block input's PLAIN tensor (and apply bn1 itself) instead of the BatchNorm'ed second
+    output (POp::bn_src).  When the block's shortcut conv is written in front of conv1, the plain tensor's last listed reader
+    comes before conv1: the planner must still keep it alive — and un-aliased — up to conv1."""
+    path = models.make_iresnet(str(tmp_path / "ds_first.onnx"), (1, 1, 1, 1), (32, 128, 128, 128), 112, 64, seed=5, downsample_first=True)
+    desc = fa.plan_describe(path, 112, 112)
+    ops = [l for l in desc.splitlines() if re.match(r"^\d+ ", l)]
+    tens = {int(m.group(1)): (int(m.group(2)) * int(m.group(3)) * int(m.group(4)), int(m.group(5)), int(m.group(6)), int(m.group(7)))
+            for m in re.finditer(r"tensor t(\d+) (\d+)x(\d+)x(\d+) off (\d+) live (-?\d+)\.\.(-?\d+)", desc)}
+    links = 0
+    for l in ops:
+        m = re.search(r"bn<-op(\d+)", l)
+        if not m:
+            continue
+        i, prod = int(l.split()[0]), int(m.group(1))
+        plain = int(re.search(r"out t(-?\d+)", ops[prod]).group(1))
+        shortcut_between = any(re.search(rf"\[in t{plain} ", ops[j]) for j in range(prod + 1, i))
+        elems, off, first, last = tens[plain]
+        assert first <= prod and last >= i, (l, tens[plain])
+        for t, (e2, o2, f2, l2) in tens.items():                      # nothing else may occupy its floats while it is live
+            if t != plain and not (l2 < first or last < f2):
+                assert o2 + e2 <= off or off + elems <= o2, (plain, t)
+        links += shortcut_between
+    assert links >= 3                                                  # the stage-opening blocks: shortcut conv sits between
