@@ -65,7 +65,61 @@ def parse():
                     "mbf = w600k_mbf (MobileFaceNet, the buffalo_s / buffalo_sc recogniser): a secondary measurement")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo only to rehearse the N>1 code path")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous rehearsal without a GPU: ranks start, meet on gloo, "
+                    "run the barrier + max-over-ranks timing protocol around EMPTY steps and rank 0 prints a line with value = null and "
+                    "\"dry_run\": true.  Not a measurement; exists so that the N > 1 launch path is testable on a CPU-only host")
     return ap.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: start the N ranks ourselves, exactly as the
+    driver would (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <same args>`), as a CHILD of this process — which has not touched the GPU (no torch.cuda / libfacehip import
+    yet; replacing a GPU-initialised process by exec is forbidden on this pool).  Rank 0's JSON line goes to our stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                 # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, rank, world):
+    """No GPU work at all: the rendezvous, the barrier + synchronise bracket and the MAX / SUM reductions of the real run."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    for _ in range(args.warmup):
+        pass
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    units = 0
+    for _ in range(args.steps):
+        units += args.frames * args.faces_per_frame
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tot, mx = float(units), dt
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        u = torch.tensor([float(units)], dtype=torch.float64); dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        mx, tot = float(t.item()), float(u.item())
+    if rank == 0:
+        print(json.dumps({"metric": "faces/sec end-to-end (detect+align+embed), batch=128 640x640", "value": None, "unit": "faces/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none", "dry_run": True,
+                          "units_all_ranks": tot, "config": {"workload": "DRY RUN: launcher + rendezvous rehearsal, no GPU work",
+                                                             "parallelism": f"frame-sharded x{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
 
 
 def rec_model(args):
@@ -75,10 +129,21 @@ def rec_model(args):
     return models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
 
 
-def cpu_baseline(det_path, rec_path, frames_np, args):
-    """Oracle (CPU restatement) on a bounded sample, 4 threads like the reference."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(det_path, rec_path, frames_np, args, threads=None):
+    """Oracle (CPU restatement) on a bounded sample: 4 threads like the reference (src/face_detector.cpp:10), or `threads`."""
     from oracle import oracle
-    threads = min(4, os.cpu_count() or 1)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads = min(4, ncpu) if threads is None else threads
     oracle.set_threads(threads)
     od, orc = oracle.OracleDetector(), oracle.OracleRecognizer()
     assert od.loadModel(det_path) and orc.loadModel(rec_path)
@@ -103,15 +168,22 @@ def cpu_baseline(det_path, rec_path, frames_np, args):
                    f"{args.faces_per_frame} face(s) per frame",
             "embed": f"{n} of the batch's 112x112 crops: preprocess + IResNet-50 + L2-normalise",
             "detect": f"{n} of the batch's 640x640 frames: SCRFD + decode + NMS"}[args.workload]
-    return {"value": faces / dt, "unit": unit, "cores": threads, "kind": "port",
+    return {"value": faces / dt, "unit": unit, "cores": threads, "kind": "port", "cpu": cpu_model_name(), "host_cores_available": ncpu,
             "sample": what + f" ({dt:.1f} s, CPU oracle = restatement of the reference, not ONNX Runtime)"}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(launch_ranks(args))                           # before anything touches the GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus})")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -261,8 +333,8 @@ def main():
             for off in range(0, q.shape[0], 256):
                 m = min(256, q.shape[0] - off)
                 gallery.topk_dev(q[off:off + m].data_ptr(), m, k, sc[off:off + m].data_ptr(), ix[off:off + m].data_ptr(), stream)
-            if world > 1:
-                fd.allgather_topk(sc.to(cdev), ix.to(cdev), k)
+            if world > 1:                             # ONE all-gather of the per-rank lists, merged by the library's kernel
+                fd.allgather_topk(sc, ix, k, comm_device=cdev)
             return n
 
     drain = locals().get("drain", lambda: 0)       # streaming form counts its faces on the device
@@ -379,7 +451,10 @@ def main():
                                         "algorithmic_gflop_per_launch": None,
                                         "algorithmic_mbytes_per_launch": by[4] / ln[4] / 1e6})
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(det_path, rec_path, host, args)
+            out["cpu_baseline"] = cpu_baseline(det_path, rec_path, host, args)                  # the reference's own setting: 4 threads
+            ncpu = out["cpu_baseline"]["host_cores_available"]
+            if ncpu > 4:                                                                        # all cores this process may use
+                out["cpu_baseline_all_cores"] = cpu_baseline(det_path, rec_path, host, args, threads=ncpu)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "fh_gallery_size": (_ll, [_vp]),
     "fh_gallery_label_dev": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "fh_gallery_topk_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "fh_topk_merge_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "fh_timing_enable": (_i, [_i]),
     "fh_timing_collect": (_i, [_vp, _vp, _vp, _vp, _i]),
     "fh_timing_collect_ops": (_i, [_vp, _vp, _vp, _i]),

@@ -360,6 +360,16 @@ int fh_gallery_topk_dev(fh_gallery* g, const float* q, int nq, int k, float* sco
     return guarded([&] { g->g.topk_dev(q, nq, k, scores, indices, S(stream)); return nq; });
 }
 
+int fh_topk_merge_dev(const float* ps, const int* pi, int nparts, int nq, int k, float* scores, int* indices, void* stream) {
+    if (!ps || !pi || !scores || !indices) return arg_error("fh_topk_merge_dev: null argument");
+    if (nparts <= 0 || nq <= 0 || k <= 0 || k > 16 || (long)nparts * k > 65536) return arg_error("fh_topk_merge_dev: bad size");
+    return guarded([&] {
+        fh::launch_topk_merge(ps, pi, nparts, nq, k, scores, indices, S(stream));
+        FH_HIP(hipGetLastError());
+        return nq;
+    });
+}
+
 // ---------------------------------------------------------------------------------- timing / tuning
 int fh_timing_enable(int on) { fh::KernelTimer::get().enabled = on != 0; return FH_OK; }
 int fh_timing_collect(double* ms, double* flops, double* bytes, long long* launches, int n) {

@@ -143,6 +143,12 @@ FH_API void fh_gallery_destroy(fh_gallery* g);
 FH_API int fh_gallery_upload(fh_gallery* g, const float* rows, long long n, int rows_on_device, long long index_base);
 FH_API int fh_gallery_topk_dev(fh_gallery* g, const float* d_queries, int nq, int k, float* d_scores, int* d_indices,
                                void* stream);
+/* Merge step of a row-SHARDED gallery (one shard per rank): d_part_scores / d_part_idx = [nparts][nq][k]
+ * per-shard top-k lists (global row indices, -1 = empty slot) as one all-gather delivers them -> the overall top-k by
+ * (score desc, index asc), the same total order and the same kernel fh_gallery_topk_dev finishes with, so a sharded
+ * gallery returns exactly the single-gallery answer.  nparts * k <= 65536. */
+FH_API int fh_topk_merge_dev(const float* d_part_scores, const int* d_part_idx, int nparts, int nq, int k, float* d_scores,
+                             int* d_indices, void* stream);
 /* The webcam loop's reference handling (src/main.cpp:211-212,229-233,253-256) for an enrolled SET instead of one
  * refFeature: enroll appends rows (the 's' key; returns the index of the first new row), label gives every query its
  * best row when (dot+1)/2 > threshold ("Match", reference threshold 0.6, strict) and -1 otherwise ("Unknown");

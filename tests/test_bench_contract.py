@@ -34,3 +34,26 @@ def test_bench_cli_accepts_the_driver_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` with no RANK in the environment must launch two ranks through torch.distributed.run
+    (the driver's own launch line) and relay rank 0's line.  --dry-run: no GPU here, so the ranks meet on gloo and go through
+    the barrier / max-over-ranks protocol around empty steps; the line says so (value null, dry_run true)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                                   # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["value"] is None and d["scaling"] == "weak"
+    assert d["units_all_ranks"] == 2 * 3 * 128                           # both ranks' units were summed
+    assert "x2" in d["config"]["parallelism"]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True,
+                         timeout=120, env=env)
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr

@@ -148,7 +148,16 @@ gb, ge = shard_range(G, rank, world)                             # row-sharded g
 sc = (q.numpy() @ gal[gb:ge].T + 1) / 2
 order = np.lexsort((np.arange(ge - gb)[None].repeat(Q, 0), -sc), axis=1)[:, :k]
 ls = np.take_along_axis(sc, order, 1).astype(np.float32); li = (order + gb).astype(np.int32)
-s, i = allgather_topk(torch.from_numpy(ls), torch.from_numpy(li), k)
+def cpu_merge(ps, pi, k):                                        # test-side checker standing in for the GPU merge kernel (no GPU here)
+    s = ps.permute(1, 0, 2).reshape(Q, -1).numpy(); i = pi.permute(1, 0, 2).reshape(Q, -1).numpy()
+    o = np.lexsort((i, -s.astype(np.float64)), axis=1)[:, :k]
+    return torch.from_numpy(np.take_along_axis(s, o, 1)), torch.from_numpy(np.take_along_axis(i, o, 1))
+s, i = allgather_topk(torch.from_numpy(ls), torch.from_numpy(li), k, merge=cpu_merge)
+try:                                                             # the product merge is a HIP kernel: on a CPU tensor it must refuse, not fall back
+    allgather_topk(torch.from_numpy(ls), torch.from_numpy(li), k)
+    raise SystemExit("merge_topk_dev accepted CPU tensors")
+except RuntimeError as e:
+    assert "HIP kernel" in str(e)
 full = (allq @ gal.T + 1) / 2
 ref = np.lexsort((np.arange(G)[None].repeat(Q, 0), -full.astype(np.float32)), axis=1)[:, :k]
 assert np.array_equal(i.numpy(), ref), (rank, i.numpy(), ref)
