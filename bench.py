@@ -256,59 +256,40 @@ def main():
             re_ = [torch.zeros((B * F, 512), device="cuda") for _ in range(RING)]
             rt = [torch.zeros(1, dtype=torch.int32, device="cuda") for _ in range(RING)]
             done = [None] * RING
-            face_acc = torch.zeros(1, dtype=torch.int64, device="cuda")
-            state = {"k": 0, "reported": 0}
+            state = {"k": 0}
             emb = re_[0]
 
             def step():
                 k = state["k"]; slot = k % RING
                 if done[slot] is not None:
                     s_det.wait_event(done[slot])                 # the slot's previous batch has been embedded
-                fa.pipeline_submit_dev(det, rec, data.data_ptr(), B, 640, 640, F, rf[slot].data_ptr(), ro[slot].data_ptr(),
-                                       re_[slot].data_ptr(), rt[slot].data_ptr(), s_det.cuda_stream, s_rec.cuda_stream,
-                                       args.score_thr, args.nms_thr)
-                with torch.cuda.stream(s_rec):
-                    face_acc.add_(rt[slot])
-                    done[slot] = torch.cuda.Event(); done[slot].record(s_rec)
+                n = fa.pipeline_submit_dev(det, rec, data.data_ptr(), B, 640, 640, F, rf[slot].data_ptr(), ro[slot].data_ptr(),
+                                           re_[slot].data_ptr(), rt[slot].data_ptr(), s_det.cuda_stream, s_rec.cuda_stream,
+                                           args.score_thr, args.nms_thr)
+                done[slot] = torch.cuda.Event(); done[slot].record(s_rec)
                 state["k"] = k + 1
-                return 0                                         # faces are counted on the device, see drain()
-
-            def drain():
-                torch.cuda.synchronize()
-                total = int(face_acc.item())
-                n = total - state["reported"]
-                state["reported"] = total
                 return n
 
     if args.from_host and args.workload == "e2e":
-        # streaming-caller shape (reference main.cpp:214-258 generalised): batch k+1 is copied H2D on a side
-        # stream while batch k computes; two device buffers, one event per direction.
+        # streaming-caller shape (reference main.cpp:214-258 generalised), through the library's own front end (fh_stream_*):
+        # batch k+1 is copied H2D on the object's copy stream while batch k computes; results are collected one batch later.
         pinned = torch.from_numpy(host).pin_memory()
-        bufs = [data, torch.empty_like(data)]
-        copy_stream = torch.cuda.Stream()
-        ready = [torch.cuda.Event(), torch.cuda.Event()]
-        freed = [torch.cuda.Event(), torch.cuda.Event()]
-        state = {"k": 0, "primed": False}
-
-        def upload(slot):
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(freed[slot])
-                bufs[slot].copy_(pinned, non_blocking=True)
-                ready[slot].record(copy_stream)
+        fstream = fa.FrameStream(det, rec, B, 640, 640, F)
+        state = {"inflight": 0}
 
         def step():                                   # noqa: F811
-            if not state["primed"]:
-                freed[0].record(); freed[1].record()
-                upload(0)
-                state["primed"] = True
-            cur = state["k"] & 1
-            upload(cur ^ 1)                           # prefetch the next batch
-            torch.cuda.current_stream().wait_event(ready[cur])
-            n = fa.pipeline_run_dev(det, rec, bufs[cur].data_ptr(), B, 640, 640, F, faces.data_ptr(), frame_of.data_ptr(),
-                                    emb.data_ptr(), args.score_thr, args.nms_thr, stream)
-            freed[cur].record()
-            state["k"] += 1
+            n = fstream.submit((pinned.data_ptr(), B), args.score_thr, args.nms_thr)
+            state["inflight"] += 1
+            if state["inflight"] == 2:                # ring of 2: retire the older batch
+                fstream.collect_count()
+                state["inflight"] -= 1
             return n
+
+        def drain():
+            while state["inflight"]:
+                fstream.collect_count()
+                state["inflight"] -= 1
+            return 0
 
     if args.gallery > 0 and args.workload != "detect":
         from facerecognizeonnx_amd import distributed as fd
@@ -337,7 +318,7 @@ def main():
                 fd.allgather_topk(sc, ix, k, comm_device=cdev)
             return n
 
-    drain = locals().get("drain", lambda: 0)       # streaming form counts its faces on the device
+    drain = locals().get("drain", lambda: 0)       # host-frame streaming form: retire the batches still in flight
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -73,6 +73,10 @@ PROTOTYPES = {
     "fh_rec_embed_faces_dev": (_i, [_vp, _vp, _i, _i, _i, _ll, _vp, _vp, _i, _vp, _vp, _vp]),
     "fh_pipeline_run_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _f, _f, _i, _vp, _vp, _vp, _vp]),
     "fh_pipeline_submit_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _ll, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fh_stream_create": (_vp, [_vp, _vp, _i, _i, _i, _i]),
+    "fh_stream_destroy": (None, [_vp]),
+    "fh_stream_submit": (_i, [_vp, _vp, _i, _f, _f]),
+    "fh_stream_collect": (_i, [_vp, _vp, _vp, _vp, _i]),
     "fh_gallery_create": (_vp, [_i]),
     "fh_gallery_destroy": (None, [_vp]),
     "fh_gallery_upload": (_i, [_vp, _vp, _ll, _i, _ll]),

@@ -195,11 +195,49 @@ def pipeline_run_dev(det: FaceDetector, rec: FaceRecognizer, frames_ptr: int, n:
 def pipeline_submit_dev(det: FaceDetector, rec: FaceRecognizer, frames_ptr: int, n: int, rows: int, cols: int,
                         faces_per_frame: int, faces_ptr: int, frame_of_ptr: int, emb_ptr: int, total_ptr: int,
                         stream_det: int, stream_rec: int, scoreThreshold: float = 0.5, nmsThreshold: float = 0.4) -> int:
-    """Asynchronous detect -> align -> embed: detector on stream_det, recogniser on stream_rec, no host sync."""
+    """Two-stream detect -> align -> embed: detector on stream_det, recogniser on stream_rec; the host waits for the
+    detector's face count only.  Returns the number of faces."""
     step = cols * 3
     return check(_lib.lib().fh_pipeline_submit_dev(det.handle, rec.handle, frames_ptr, n, rows, cols, step, rows * step,
                                                    scoreThreshold, nmsThreshold, faces_per_frame, faces_ptr, frame_of_ptr,
                                                    emb_ptr, total_ptr, stream_det, stream_rec), "fh_pipeline_submit_dev")
+
+
+class FrameStream:
+    """Streaming front end for batches of HOST frames (fh_stream_*): the reference's webcam loop (src/main.cpp:214-258) over
+    batches.  submit() uploads + queues a batch and returns its face count, collect() returns the oldest batch's results."""
+
+    def __init__(self, det: FaceDetector, rec: FaceRecognizer, frames_per_batch: int, rows: int, cols: int, faces_per_frame: int = 1):
+        self._h = _lib.lib().fh_stream_create(det.handle, rec.handle, frames_per_batch, rows, cols, faces_per_frame)
+        if not self._h:
+            raise _lib.FaceHipError("fh_stream_create failed: " + _lib.last_error())
+        self._keep = (det, rec)
+        self.cap = frames_per_batch * faces_per_frame
+        self.dim = rec.feature_dim()
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(_lib, "_LIB", None) is not None:
+            _lib._LIB.fh_stream_destroy(self._h)
+        self._h = None
+
+    __del__ = close
+
+    def submit(self, frames, scoreThreshold: float = 0.5, nmsThreshold: float = 0.4) -> int:
+        """frames: contiguous uint8 [n, rows, cols, 3] BGR (a numpy array, or an int pointer with n given as frames[1])."""
+        if isinstance(frames, tuple):
+            ptr, n = frames
+        else:
+            a = np.ascontiguousarray(frames, np.uint8)
+            ptr, n = a.ctypes.data, a.shape[0]
+        return check(_lib.lib().fh_stream_submit(self._h, ptr, n, scoreThreshold, nmsThreshold), "fh_stream_submit")
+
+    def collect(self):
+        faces = np.zeros(self.cap, FACE_DTYPE); frame_of = np.zeros(self.cap, np.int32); emb = np.zeros((self.cap, self.dim), np.float32)
+        n = check(_lib.lib().fh_stream_collect(self._h, faces.ctypes.data, frame_of.ctypes.data, emb.ctypes.data, self.cap), "fh_stream_collect")
+        return faces[:n], frame_of[:n], emb[:n]
+
+    def collect_count(self) -> int:
+        return check(_lib.lib().fh_stream_collect(self._h, None, None, None, 0), "fh_stream_collect")
 
 
 class Gallery:

@@ -42,8 +42,9 @@ struct fh_det {
     fh::Detector det;
     fh::DevBuf img, out, cnt;            // staging for the host-pointer API
     fh::DevBuf p_det, p_cnt, p_total;    // pipeline scratch
-    hipEvent_t ev_sel = nullptr;         // detect -> embed hand-off between two streams
-    ~fh_det() { if (ev_sel) (void)hipEventDestroy(ev_sel); }
+    hipEvent_t ev_sel = nullptr;         // detect -> embed hand-off (face count known / stream_rec may start)
+    int* h_total = nullptr;              // pinned landing word of the face count
+    ~fh_det() { if (ev_sel) (void)hipEventDestroy(ev_sel); if (h_total) (void)hipHostFree(h_total); }
 };
 struct fh_rec {
     explicit fh_rec(const char* p) : rec(p) {}
@@ -283,34 +284,42 @@ float fh_compare(const float* f1, int n1, const float* f2, int n2) {
 }
 
 // ---------------------------------------------------------------------------------- pipeline
+namespace {
+// detect + decode + NMS + face selection on stream sd, then the ONE host hand-off of the pipeline: the number of live faces
+// (4 bytes through pinned memory, behind an event on sd).  Everything after it — align + embed — is sized by that count, so
+// the recogniser never runs on empty slots (the reference embeds "for every face", src/main.cpp:221-238: 0..F per frame).
+int detect_select_count(fh_det* d, const uint8_t* frames, int n, int rows, int cols, int step, long stride, float score_thr, float nms_thr,
+                        int F, fh_face* faces, int* frame_of, int* d_total, hipStream_t sd) {
+    d->p_det.ensure((size_t)n * F * sizeof(fh_face));
+    d->p_cnt.ensure((size_t)n * sizeof(int));
+    d->p_total.ensure(sizeof(int));
+    if (!d->ev_sel) FH_HIP(hipEventCreateWithFlags(&d->ev_sel, hipEventDisableTiming));
+    if (!d->h_total) FH_HIP(hipHostMalloc(reinterpret_cast<void**>(&d->h_total), sizeof(int), hipHostMallocDefault));
+    int* dt = d_total ? d_total : d->p_total.as<int>();
+    d->det.detect_dev(frames, n, rows, cols, step, stride, score_thr, nms_thr, d->p_det.as<fh::FaceRec>(), F, d->p_cnt.as<int>(), sd);
+    fh::launch_select_faces(d->p_det.as<fh::FaceRec>(), d->p_cnt.as<int>(), n, F, F, reinterpret_cast<fh::FaceRec*>(faces), frame_of, dt, sd);
+    FH_HIP(hipMemcpyAsync(d->h_total, dt, sizeof(int), hipMemcpyDeviceToHost, sd));
+    FH_HIP(hipEventRecord(d->ev_sel, sd));
+    FH_HIP(hipEventSynchronize(d->ev_sel));               // waits for the DETECTOR of this batch only; a recogniser queued earlier on another stream keeps running
+    return *d->h_total;
+}
+}  // namespace
+
 int fh_pipeline_run_dev(fh_det* d, fh_rec* r, const uint8_t* frames, int n, int rows, int cols, int step, long long stride,
                         float score_thr, float nms_thr, int F, fh_face* faces, int* frame_of, float* emb, void* stream) {
     if (!d || !r || !frames || !faces || !frame_of || !emb) return arg_error("fh_pipeline_run_dev: null argument");
     if (n <= 0 || n > 4096 || rows <= 0 || cols <= 0 || F <= 0) return arg_error("fh_pipeline_run_dev: bad size");
     return guarded([&] {
         hipStream_t s = S(stream);
-        d->p_det.ensure((size_t)n * F * sizeof(fh_face));
-        d->p_cnt.ensure((size_t)n * sizeof(int));
-        d->p_total.ensure(sizeof(int));
-        d->det.detect_dev(frames, n, rows, cols, step, (long)stride, score_thr, nms_thr, d->p_det.as<fh::FaceRec>(), F, d->p_cnt.as<int>(), s);
-        fh::launch_select_faces(d->p_det.as<fh::FaceRec>(), d->p_cnt.as<int>(), n, F, F, reinterpret_cast<fh::FaceRec*>(faces), frame_of,
-                                d->p_total.as<int>(), s);
-        // No host round trip between detect and embed: all n*F slots are launched, slots beyond the
-        // device-side face count are emptied by the align kernel (ok = 0) and their embeddings are
-        // never reported.  The one synchronisation is at the end, to return the count.
-        r->rec.embed_faces_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, n * F, emb,
-                               nullptr, s, d->p_total.as<int>());
-        int total = 0;
-        FH_HIP(hipMemcpyAsync(&total, d->p_total.p, sizeof(int), hipMemcpyDeviceToHost, s));
-        FH_HIP(hipStreamSynchronize(s));
+        const int total = detect_select_count(d, frames, n, rows, cols, step, (long)stride, score_thr, nms_thr, F, faces, frame_of, nullptr, s);
+        r->rec.embed_faces_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, total, emb, nullptr, s);
         return total;
     });
 }
 
-// Fully asynchronous form for streaming callers: detect (+ decode + NMS + face selection) is queued on
-// stream_det, align + embed on stream_rec behind an event, nothing synchronises with the host and the
-// face count stays on the device (d_total).  Submitting batch k+1 right after batch k lets the
-// HBM-bound detector of k+1 run beside the MFMA-bound recogniser of k on the same GPU.
+// Two-stream form for streaming callers: detect (+ decode + NMS + face selection) on stream_det, align + embed on stream_rec
+// behind an event.  The host waits for the detector's face count only, so with batch k+1 submitted straight after batch k the
+// HBM-bound detector of k+1 runs beside the MFMA-bound recogniser of k.
 int fh_pipeline_submit_dev(fh_det* d, fh_rec* r, const uint8_t* frames, int n, int rows, int cols, int step, long long stride,
                            float score_thr, float nms_thr, int F, fh_face* faces, int* frame_of, float* emb, int* d_total,
                            void* stream_det, void* stream_rec) {
@@ -318,19 +327,101 @@ int fh_pipeline_submit_dev(fh_det* d, fh_rec* r, const uint8_t* frames, int n, i
     if (n <= 0 || n > 4096 || rows <= 0 || cols <= 0 || F <= 0) return arg_error("fh_pipeline_submit_dev: bad size");
     return guarded([&] {
         hipStream_t sd = S(stream_det), sr = S(stream_rec);
-        d->p_det.ensure((size_t)n * F * sizeof(fh_face));
-        d->p_cnt.ensure((size_t)n * sizeof(int));
-        if (!d->ev_sel) FH_HIP(hipEventCreateWithFlags(&d->ev_sel, hipEventDisableTiming));
-        d->det.detect_dev(frames, n, rows, cols, step, (long)stride, score_thr, nms_thr, d->p_det.as<fh::FaceRec>(), F, d->p_cnt.as<int>(), sd);
-        fh::launch_select_faces(d->p_det.as<fh::FaceRec>(), d->p_cnt.as<int>(), n, F, F, reinterpret_cast<fh::FaceRec*>(faces), frame_of,
-                                d_total, sd);
-        if (sd != sr) {
-            FH_HIP(hipEventRecord(d->ev_sel, sd));
-            FH_HIP(hipStreamWaitEvent(sr, d->ev_sel, 0));
+        const int total = detect_select_count(d, frames, n, rows, cols, step, (long)stride, score_thr, nms_thr, F, faces, frame_of, d_total, sd);
+        if (sd != sr) FH_HIP(hipStreamWaitEvent(sr, d->ev_sel, 0));
+        r->rec.embed_faces_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, total, emb, nullptr, sr);
+        return total;
+    });
+}
+
+// ---------------------------------------------------------------------------------- streaming front end (host frames)
+// The caller of the path (reference testWebcam, src/main.cpp:214-258: grab a frame, detect, embed every face, compare) over
+// BATCHES of host frames: a ring of device slots, uploads on a copy stream while the previous batch computes, results
+// fetched one batch later.  All device memory, streams and events belong to the object.
+struct fh_stream {
+    static constexpr int kSlots = 2;
+    fh_det* det; fh_rec* rec;
+    int n, rows, cols, F, dim;
+    size_t frame_bytes;
+    hipStream_t copy_s = nullptr, comp_s = nullptr;
+    struct Slot {
+        fh::DevBuf frames, faces, frame_of, emb;
+        hipEvent_t uploaded = nullptr, done = nullptr;
+        int total = -1;                       // faces of the batch in flight (-1 = slot free)
+        int frames_in = 0;
+    } slot[kSlots];
+    long submitted = 0, collected = 0;
+    fh_stream(fh_det* d, fh_rec* r, int n_, int rows_, int cols_, int F_) : det(d), rec(r), n(n_), rows(rows_), cols(cols_), F(F_) {
+        dim = r->rec.dim();
+        frame_bytes = (size_t)rows * cols * 3;
+        FH_HIP(hipStreamCreateWithFlags(&copy_s, hipStreamNonBlocking));
+        FH_HIP(hipStreamCreateWithFlags(&comp_s, hipStreamNonBlocking));
+        for (auto& sl : slot) {
+            sl.frames.ensure((size_t)n * frame_bytes);
+            sl.faces.ensure((size_t)n * F * sizeof(fh_face));
+            sl.frame_of.ensure((size_t)n * F * sizeof(int));
+            sl.emb.ensure((size_t)n * F * dim * sizeof(float));
+            FH_HIP(hipEventCreateWithFlags(&sl.uploaded, hipEventDisableTiming));
+            FH_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         }
-        r->rec.embed_faces_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, n * F, emb,
-                               nullptr, sr, d_total);
-        return n * F;
+    }
+    ~fh_stream() {
+        (void)hipDeviceSynchronize();
+        for (auto& sl : slot) { if (sl.uploaded) (void)hipEventDestroy(sl.uploaded); if (sl.done) (void)hipEventDestroy(sl.done); }
+        if (copy_s) (void)hipStreamDestroy(copy_s);
+        if (comp_s) (void)hipStreamDestroy(comp_s);
+    }
+};
+
+fh_stream* fh_stream_create(fh_det* d, fh_rec* r, int frames_per_batch, int rows, int cols, int faces_per_frame) {
+    if (!d || !r || frames_per_batch <= 0 || frames_per_batch > 4096 || rows <= 0 || cols <= 0 || faces_per_frame <= 0) {
+        g_err = "fh_stream_create: bad argument";
+        return nullptr;
+    }
+    fh_stream* h = nullptr;
+    const int rc = guarded([&] { h = new fh_stream(d, r, frames_per_batch, rows, cols, faces_per_frame); return 0; });
+    return rc == 0 ? h : nullptr;
+}
+void fh_stream_destroy(fh_stream* s) { delete s; }
+
+int fh_stream_submit(fh_stream* st, const uint8_t* host_frames, int n_frames, float score_thr, float nms_thr) {
+    if (!st || !host_frames) return arg_error("fh_stream_submit: null argument");
+    if (n_frames <= 0 || n_frames > st->n) return arg_error("fh_stream_submit: batch larger than the stream was created for");
+    if (st->submitted - st->collected >= fh_stream::kSlots) { g_err = "fh_stream_submit: ring full, collect a batch first"; return FH_ERR_STATE; }
+    return guarded([&] {
+        fh_stream::Slot& sl = st->slot[st->submitted % fh_stream::kSlots];
+        // upload on the copy stream (overlaps the batch computing on comp_s), compute behind the upload's event
+        FH_HIP(hipMemcpyAsync(sl.frames.p, host_frames, (size_t)n_frames * st->frame_bytes, hipMemcpyHostToDevice, st->copy_s));
+        FH_HIP(hipEventRecord(sl.uploaded, st->copy_s));
+        FH_HIP(hipStreamWaitEvent(st->comp_s, sl.uploaded, 0));
+        const int step = st->cols * 3;
+        const int total = detect_select_count(st->det, sl.frames.as<uint8_t>(), n_frames, st->rows, st->cols, step, (long)st->frame_bytes, score_thr, nms_thr,
+                                              st->F, sl.faces.as<fh_face>(), sl.frame_of.as<int>(), nullptr, st->comp_s);
+        st->rec->rec.embed_faces_dev(sl.frames.as<uint8_t>(), st->rows, st->cols, step, (long)st->frame_bytes, sl.faces.as<fh::FaceRec>(),
+                                     sl.frame_of.as<int>(), total, sl.emb.as<float>(), nullptr, st->comp_s);
+        FH_HIP(hipEventRecord(sl.done, st->comp_s));
+        sl.total = total; sl.frames_in = n_frames;
+        ++st->submitted;
+        return total;
+    });
+}
+
+int fh_stream_collect(fh_stream* st, fh_face* faces, int* frame_of, float* emb, int cap) {
+    if (!st) return arg_error("fh_stream_collect: null handle");
+    if (st->collected >= st->submitted) { g_err = "fh_stream_collect: nothing in flight"; return FH_ERR_STATE; }
+    return guarded([&] {
+        fh_stream::Slot& sl = st->slot[st->collected % fh_stream::kSlots];
+        FH_HIP(hipEventSynchronize(sl.done));
+        const int m = sl.total < cap ? sl.total : cap;
+        if (m > 0) {
+            if (faces) FH_HIP(hipMemcpy(faces, sl.faces.p, (size_t)m * sizeof(fh_face), hipMemcpyDeviceToHost));
+            if (frame_of) FH_HIP(hipMemcpy(frame_of, sl.frame_of.p, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
+            if (emb) FH_HIP(hipMemcpy(emb, sl.emb.p, (size_t)m * st->dim * sizeof(float), hipMemcpyDeviceToHost));
+        }
+        const int total = sl.total;
+        sl.total = -1;
+        ++st->collected;
+        return total;
     });
 }
 

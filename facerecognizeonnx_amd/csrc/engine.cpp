@@ -401,19 +401,19 @@ void Recognizer::embed_aligned_dev(const uint8_t* crops, int n, float* out, hipS
 }
 
 void Recognizer::align_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces,
-                           const int* frame_of, int n, uint8_t* crops, int* ok, hipStream_t s, const int* live) {
-    launch_align(frames, stride, rows, cols, step, faces, frame_of, n, net_.in_h(), net_.in_w(), crops, ok, s, live);
+                           const int* frame_of, int n, uint8_t* crops, int* ok, hipStream_t s) {
+    launch_align(frames, stride, rows, cols, step, faces, frame_of, n, net_.in_h(), net_.in_w(), crops, ok, s);
     FH_HIP(hipGetLastError());
 }
 
 void Recognizer::embed_faces_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces,
-                                 const int* frame_of, int n, float* out, int* ok, hipStream_t s, const int* live) {
+                                 const int* frame_of, int n, float* out, int* ok, hipStream_t s) {
     if (n <= 0) return;
     const size_t crop = (size_t)net_.in_h() * net_.in_w() * 3;
     crops_.ensure((size_t)n * crop);
     ok_.ensure((size_t)n * sizeof(int));
     int* okp = ok ? ok : ok_.as<int>();
-    align_dev(frames, rows, cols, step, stride, faces, frame_of, n, crops_.as<uint8_t>(), okp, s, live);
+    align_dev(frames, rows, cols, step, stride, faces, frame_of, n, crops_.as<uint8_t>(), okp, s);
     embed_aligned_dev(crops_.as<uint8_t>(), n, out, s);
 }
 

@@ -104,9 +104,9 @@ class Recognizer {
     void embed_aligned_dev(const uint8_t* crops, int n, float* out, hipStream_t s, float* raw_out = nullptr);
     // alignFace + embed: faces[n] (device) on frames; ok[n] (device, may be null) 1/2 = produced, 0 = empty
     void embed_faces_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces,
-                         const int* frame_of, int n, float* out, int* ok, hipStream_t s, const int* live = nullptr);
+                         const int* frame_of, int n, float* out, int* ok, hipStream_t s);
     void align_dev(const uint8_t* frames, int rows, int cols, int step, long stride, const FaceRec* faces, const int* frame_of,
-                   int n, uint8_t* crops, int* ok, hipStream_t s, const int* live = nullptr);
+                   int n, uint8_t* crops, int* ok, hipStream_t s);
     void resize_embed_dev(const uint8_t* frames, int n, int rows, int cols, int step, long stride, float* out, hipStream_t s);
     int max_chunk = 256;                                 // faces per network pass
 

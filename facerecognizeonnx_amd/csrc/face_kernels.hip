@@ -359,21 +359,16 @@ constexpr int ALIGN_PARTS = 4;
 
 __global__ __launch_bounds__(256) void align_kernel(const uint8_t* __restrict__ frames, long img_stride, int rows, int cols, int step,
                                                     const FaceRec* __restrict__ faces, const int* __restrict__ frame_of, int outH,
-                                                    int outW, uint8_t* __restrict__ crops, int* __restrict__ ok,
-                                                    const int* __restrict__ live) {
+                                                    int outW, uint8_t* __restrict__ crops, int* __restrict__ ok) {
     __shared__ double Ms[6];
     __shared__ int mode;          // 1 warp, 2 crop-resize, 0 empty
     __shared__ int cbox[4];
     // ALIGN_PARTS workgroups per face: each repeats the (serial, fp64) transform estimate and warps its share of the pixels —
     // with one workgroup per face a 128-face batch left half the CUs idle behind that serial section
     const int n = blockIdx.x / ALIGN_PARTS, part = blockIdx.x - n * ALIGN_PARTS, tid = threadIdx.x;
-    // `live` (device-side face count) lets a pipeline launch a fixed number of slots without a host
-    // round trip; slots beyond it produce an empty (all-zero) crop and ok = 0.
-    const bool dead = live && n >= live[0];
-    const FaceRec face = dead ? FaceRec{} : faces[n];
-    const uint8_t* img = frames + (size_t)(dead ? 0 : (frame_of ? frame_of[n] : n)) * img_stride;
-    if (tid == 0 && dead) { mode = 0; if (part == 0) ok[n] = 0; }
-    if (tid == 0 && !dead) {
+    const FaceRec face = faces[n];
+    const uint8_t* img = frames + (size_t)(frame_of ? frame_of[n] : n) * img_stride;
+    if (tid == 0) {
         const float tmpl[10] = {38.2946f, 51.6963f, 73.5318f, 51.5014f, 56.0252f, 71.7366f, 41.5493f, 92.3655f, 70.7299f, 92.2041f};
         double M[6];
         if (estimate_similarity5(face.lm, tmpl, M)) {
@@ -437,9 +432,9 @@ __global__ __launch_bounds__(256) void align_kernel(const uint8_t* __restrict__ 
 }
 
 void launch_align(const uint8_t* frames, long img_stride, int rows, int cols, int step, const FaceRec* faces, const int* frame_of,
-                  int n, int outH, int outW, uint8_t* crops, int* ok, hipStream_t s, const int* live) {
+                  int n, int outH, int outW, uint8_t* crops, int* ok, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(align_kernel, dim3(n * ALIGN_PARTS), dim3(256), 0, s, frames, img_stride, rows, cols, step, faces, frame_of, outH, outW, crops, ok, live);
+    hipLaunchKernelGGL(align_kernel, dim3(n * ALIGN_PARTS), dim3(256), 0, s, frames, img_stride, rows, cols, step, faces, frame_of, outH, outW, crops, ok);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -156,8 +156,7 @@ void launch_sort_nms(const FaceRec* cand, unsigned long long* keys, const int* c
 // FaceRecognizer::alignFace (src/face_recognizer.cpp:93-133): similarity estimate + warpAffine
 //   faces[n] with frame index frame_of[n]; writes crops [n,112,112,3] BGR u8 and ok[n].
 void launch_align(const uint8_t* frames, long img_stride, int rows, int cols, int step, const FaceRec* faces,
-                  const int* frame_of, int n, int outH, int outW, uint8_t* crops, int* ok, hipStream_t s,
-                  const int* live = nullptr);   // live[0] (device) = number of valid faces, slots beyond it are emptied
+                  const int* frame_of, int n, int outH, int outW, uint8_t* crops, int* ok, hipStream_t s);
 void launch_resize_u8c3(const uint8_t* src, long src_stride, int sh, int sw, int sstep, uint8_t* dst, long dst_stride,
                         int dh, int dw, int dstep, int n, hipStream_t s);
 

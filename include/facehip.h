@@ -117,25 +117,37 @@ FH_API int fh_rec_embed_faces_dev(fh_rec* r, const uint8_t* d_frames, int rows, 
                                   float* d_out, int* d_ok, void* stream);
 
 /* ---- detect -> align -> embed on a batch of HBM-resident frames (the headline metric path).
- * Takes the first min(count, faces_per_frame) faces of each frame (score order).  d_faces /
- * d_frame_of / d_emb must hold n*faces_per_frame entries; the compacted face list is written
- * front-to-back.  Returns the number of faces embedded (synchronises the stream once to learn
- * it) or < 0. */
+ * Takes the first min(count, faces_per_frame) faces of each frame (score order) — the reference embeds "for every face"
+ * (src/main.cpp:221-238).  d_faces / d_frame_of / d_emb must hold n*faces_per_frame entries; the compacted face list is
+ * written front-to-back.  ONE host hand-off: after detect + NMS + selection the face count comes back through pinned memory
+ * (the call waits for the detector only), and align + embed are then launched on exactly that many faces — dead slots cost
+ * nothing.  Returns the number of faces (>= 0) or < 0; the embeddings are complete when `stream` has drained. */
 FH_API int fh_pipeline_run_dev(fh_det* d, fh_rec* r, const uint8_t* d_frames, int n, int rows, int cols, int step,
                                long long frame_stride, float score_thr, float nms_thr, int faces_per_frame,
                                fh_face* d_faces, int* d_frame_of, float* d_emb, void* stream);
 
-/* Asynchronous form for streaming callers (the testWebcam loop shape, src/main.cpp:214-258, over batches):
- * detect + decode + NMS + face selection are queued on stream_det, align + embed on stream_rec behind an
- * event; nothing synchronises with the host.  d_total (device int) receives the number of faces; all
- * n*faces_per_frame embedding slots are computed, slots >= *d_total are empty.  Every buffer passed in
- * (frames included) must stay untouched until stream_rec has drained; give each in-flight batch its own
- * d_faces / d_frame_of / d_emb / d_total.  Submitting batch k+1 straight after batch k overlaps the
- * HBM-bound detector with the MFMA-bound recogniser.  Returns the number of slots or < 0. */
+/* Two-stream form for streaming callers (the testWebcam loop shape, src/main.cpp:214-258, over batches): detect + decode +
+ * NMS + face selection on stream_det, align + embed on stream_rec behind an event.  The host waits for the detector's face
+ * count only; a recogniser queued earlier on stream_rec keeps running, so submitting batch k+1 straight after batch k
+ * overlaps the HBM-bound detector with the MFMA-bound recogniser.  d_total (device int) also receives the count.  Every
+ * buffer passed in (frames included) must stay untouched until stream_rec has drained; give each in-flight batch its own
+ * d_faces / d_frame_of / d_emb / d_total.  Returns the number of faces or < 0. */
 FH_API int fh_pipeline_submit_dev(fh_det* d, fh_rec* r, const uint8_t* d_frames, int n, int rows, int cols, int step,
                                   long long frame_stride, float score_thr, float nms_thr, int faces_per_frame,
                                   fh_face* d_faces, int* d_frame_of, float* d_emb, int* d_total, void* stream_det,
                                   void* stream_rec);
+
+/* ---- streaming front end for HOST frames: the caller of the path (testWebcam, src/main.cpp:214-258: grab, detect, embed
+ * every face) over batches.  The object owns a 2-slot ring of device buffers, a copy stream and a compute stream:
+ * fh_stream_submit uploads the batch (tightly packed [n_frames][rows][cols][3] BGR u8; pinned memory makes the copy truly
+ * asynchronous) while the previous batch is still computing, queues detect -> align -> embed behind it and returns the
+ * batch's face count; fh_stream_collect waits for the OLDEST batch in flight and copies out its first min(count, cap)
+ * faces / frame indices / embeddings (any of the three pointers may be NULL).  At most 2 batches in flight. */
+typedef struct fh_stream fh_stream;
+FH_API fh_stream* fh_stream_create(fh_det* d, fh_rec* r, int frames_per_batch, int rows, int cols, int faces_per_frame);
+FH_API void fh_stream_destroy(fh_stream* s);
+FH_API int fh_stream_submit(fh_stream* s, const uint8_t* host_frames, int n_frames, float score_thr, float nms_thr);
+FH_API int fh_stream_collect(fh_stream* s, fh_face* faces, int* frame_of, float* emb, int cap);
 
 /* ---- gallery (1:N compareFaces): rows are L2-normalised features; scores are (dot+1)/2. */
 FH_API fh_gallery* fh_gallery_create(int dim);

@@ -679,8 +679,8 @@ def test_cli_modes(models_dir, tmp_path, capsys):
 
 
 def test_async_two_stream_pipeline_equals_serial(models_dir):
-    """fh_pipeline_submit_dev (detector and recogniser on different HIP streams, several batches in flight, no host
-    sync) must give exactly the serial entry point's faces and embeddings."""
+    """fh_pipeline_submit_dev (detector and recogniser on different HIP streams, several batches in flight, the host waiting
+    for the detector's face count only) must give exactly the serial entry point's faces and embeddings."""
     det = fa.FaceDetector(); rec = fa.FaceRecognizer()
     assert det.loadModel(util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0)) and rec.loadModel(util.tiny_iresnet(models_dir))
     n, F, K = 5, 3, 4
@@ -698,7 +698,7 @@ def test_async_two_stream_pipeline_equals_serial(models_dir):
         e = torch.zeros((n * F, 512), device="cuda"); t = torch.zeros(1, dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         assert fa.pipeline_submit_dev(det, rec, batches[k].data_ptr(), n, 128, 128, F, f.data_ptr(), o.data_ptr(), e.data_ptr(),
-                                      t.data_ptr(), sd.cuda_stream, sr.cuda_stream) == n * F
+                                      t.data_ptr(), sd.cuda_stream, sr.cuda_stream) == ref[k][0]
         outs.append((t, f, o, e))
     torch.cuda.synchronize()
     for (t, f, o, e), (rt, rf, ro, re_) in zip(outs, ref):
@@ -1014,3 +1014,96 @@ def test_bench_two_ranks_on_one_gpu_through_the_launcher():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["gallery_rows"] == 50000
     assert abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2 * 1e-3)) / d["value"] < 1e-6      # faces of BOTH ranks / max-over-ranks time
+
+
+def test_pipeline_embeds_live_faces_only(models_dir):
+    """The reference embeds "for every face" (main.cpp:221-238): 0..F per frame.  The pipeline must hand the recogniser exactly
+    the live faces (compacted, frame order kept), give the serial per-face API's embeddings, and spend recogniser time in
+    proportion to them — a batch of empty frames costs (almost) nothing."""
+    from facerecognizeonnx_amd.synth import models
+    det = fa.FaceDetector(); rec = fa.FaceRecognizer()
+    assert det.loadModel(util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0))
+    assert rec.loadModel(models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50))
+    n, F = 32, 4
+    frames = util.frames_u8(n, 128, 128, seed=90, smooth=True)
+    frames[::3] = 0                                                      # every third frame: nothing to detect
+    # pick a threshold that leaves a MIX of 0..F faces per frame
+    allf = torch.zeros((n, 64, 15), device="cuda"); cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    fd = dev(frames)
+    det.detect_batch_dev(fd.data_ptr(), n, 128, 128, allf.data_ptr(), 64, cnt.data_ptr(), 0.3, 0.4)
+    torch.cuda.synchronize()
+    recs = _records(allf, n, 64); c0 = cnt.cpu().numpy()
+    second = sorted(float(recs[b, 1]["score"]) for b in range(n) if c0[b] >= 2)
+    assert len(second) >= 8
+    thr = second[len(second) // 2] + 1e-6
+    det.detect_batch_dev(fd.data_ptr(), n, 128, 128, allf.data_ptr(), 64, cnt.data_ptr(), thr, 0.4)
+    torch.cuda.synchronize()
+    want = np.minimum(cnt.cpu().numpy(), F)
+    assert want.min() == 0 and want.max() >= 2 and 0 < want.sum() < n * F and len(set(want.tolist())) >= 3, want
+    faces = torch.zeros((n * F, 15), device="cuda"); fo = torch.full((n * F,), -1, dtype=torch.int32, device="cuda")
+    emb = torch.zeros((n * F, 512), device="cuda")
+    total = fa.pipeline_run_dev(det, rec, fd.data_ptr(), n, 128, 128, F, faces.data_ptr(), fo.data_ptr(), emb.data_ptr(), thr, 0.4)
+    torch.cuda.synchronize()
+    assert total == int(want.sum())
+    got_fo = fo.cpu().numpy()[:total]
+    assert np.array_equal(got_fo, np.repeat(np.arange(n), want))         # compacted, frame order, min(count, F) each
+    # serial API on the same faces: one face at a time through fh_rec_embed_faces_dev
+    ser = torch.zeros((total, 512), device="cuda")
+    for i in range(total):
+        one = faces[i:i + 1].contiguous(); fo1 = fo[i:i + 1].contiguous()
+        assert fa.lib().fh_rec_embed_faces_dev(rec.handle, fd.data_ptr(), 128, 128, 384, 128 * 384, one.data_ptr(), fo1.data_ptr(), 1,
+                                               ser[i:i + 1].data_ptr(), 0, 0) == 1
+    torch.cuda.synchronize()
+    a, b = emb[:total].cpu().numpy().astype(np.float64), ser.cpu().numpy().astype(np.float64)
+    assert (1.0 - (a * b).sum(1)).max() < 1e-6                           # batch of `total` vs batch of 1: fp32 summation order only
+    assert torch.all(emb[total:] == 0)                                   # slots beyond the live faces are never written
+
+    def timed(thr_):
+        for _ in range(2):
+            t = fa.pipeline_run_dev(det, rec, fd.data_ptr(), n, 128, 128, F, faces.data_ptr(), fo.data_ptr(), emb.data_ptr(), thr_, 0.4)
+        torch.cuda.synchronize()
+        a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a_.record()
+        for _ in range(5):
+            fa.pipeline_run_dev(det, rec, fd.data_ptr(), n, 128, 128, F, faces.data_ptr(), fo.data_ptr(), emb.data_ptr(), thr_, 0.4)
+        b_.record(); torch.cuda.synchronize()
+        return t, a_.elapsed_time(b_) / 5
+    t_full, ms_full = timed(0.05)                                        # every non-empty frame has >= F faces
+    t_none, ms_none = timed(1.0)                                         # nothing passes
+    t_mix, ms_mix = timed(thr)
+    assert t_none == 0 and t_full > 2 * t_mix > 0
+    assert ms_none < 0.25 * ms_full and ms_mix < 0.75 * ms_full, (ms_none, ms_mix, ms_full, t_mix, t_full)
+
+
+def test_frame_stream_equals_device_pipeline(models_dir):
+    """fh_stream_* (host frames, uploads overlapped with the previous batch, results one batch later) returns exactly what
+    fh_pipeline_run_dev returns for the same frames resident in HBM; ring-full / empty-ring states are errors, not hangs."""
+    det = fa.FaceDetector(); rec = fa.FaceRecognizer()
+    assert det.loadModel(util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0)) and rec.loadModel(util.tiny_iresnet(models_dir))
+    n, F, K = 6, 2, 5
+    batches = [util.frames_u8(n if k != 3 else 4, 128, 128, seed=70 + k, smooth=True) for k in range(K)]      # one short batch
+    ref = []
+    for fr in batches:
+        m = len(fr)
+        f = torch.zeros((m * F, 15), device="cuda"); o = torch.zeros(m * F, dtype=torch.int32, device="cuda"); e = torch.zeros((m * F, 512), device="cuda")
+        t = fa.pipeline_run_dev(det, rec, dev(fr).data_ptr(), m, 128, 128, F, f.data_ptr(), o.data_ptr(), e.data_ptr())
+        torch.cuda.synchronize()
+        ref.append((t, _records(f.view(1, m * F, 15), 1, m * F)[0][:t], o.cpu().numpy()[:t], e.cpu().numpy()[:t]))
+    st = fa.FrameStream(det, rec, n, 128, 128, F)
+    with pytest.raises(fa.FaceHipError):
+        st.collect()                                                     # nothing in flight
+    got = []
+    for k, fr in enumerate(batches):
+        assert st.submit(fr) == ref[k][0]
+        if k >= 1:
+            got.append(st.collect())                                     # batch k-1, while batch k is in flight
+        if k == 0:
+            assert st.submit(batches[1]) == ref[1][0]                    # fill the ring ...
+            with pytest.raises(fa.FaceHipError):
+                st.submit(batches[2])                                    # ... a third batch must be refused
+            got.append(st.collect()); st.collect()                       # retire both; batch 1 is submitted again by the loop
+    got.append(st.collect())
+    assert len(got) == K
+    for (t, rf, ro, re_), (gf, go, ge) in zip(ref, got):
+        assert len(gf) == t and gf.tobytes() == rf.tobytes() and np.array_equal(go, ro) and np.array_equal(ge, re_)
+    st.close()
