@@ -151,6 +151,21 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
                 for (int t = 0; t < 9; ++t)
                     for (int ci = 0; ci < 3; ++ci) w27[(size_t)(t * 3 + ci) * op.Cout + co] = op.weight[((size_t)co * 9 + t) * 4 + ci];
             dev_[0].w27 = push(w27.data(), w27.size());
+            // the same filter with (v - 127.5) / 128 folded in, in the byte order of a BGR pixel (thread-per-pixel stem kernel):
+            // w / 128 is exact (power of two); the constant part goes to the bias in fp64
+            std::vector<float> wf((size_t)27 * op.Cout), bf((size_t)op.Cout);
+            for (int co = 0; co < op.Cout; ++co) {
+                double sum = 0;
+                for (int t = 0; t < 9; ++t)
+                    for (int j = 0; j < 3; ++j) {
+                        const float w = op.weight[((size_t)co * 9 + t) * 4 + (2 - j)];
+                        wf[(size_t)(t * 3 + j) * op.Cout + co] = w / 128.0f;
+                        sum += w;
+                    }
+                bf[co] = (float)((double)op.bias[co] - 127.5 / 128.0 * sum);
+            }
+            dev_[0].wf = push(wf.data(), wf.size());
+            dev_[0].bf = push(bf.data(), bf.size());
         }
     }
     params_.ensure(std::max<size_t>(host.size(), 64) * sizeof(float));
@@ -185,8 +200,8 @@ void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int st
         const float* P = params_.as<float>();
         KernelTimer& timer = KernelTimer::get();
         timer.begin(s);
-        launch_stem_conv_u8(src, img_stride, srcH, srcW, step, batch, plan_.inH, plan_.inW, op.stride, op.Cout, P + d.w27, P + d.bias,
-                            d.has_slope ? P + d.slope : nullptr, (int)op.act, op.out >= 0 ? tensor_ptr(op.out) : nullptr,
+        launch_stem_conv_u8(src, img_stride, srcH, srcW, step, batch, plan_.inH, plan_.inW, op.stride, op.Cout, P + d.w27, P + d.bias, P + d.wf,
+                            P + d.bf, d.has_slope ? P + d.slope : nullptr, (int)op.act, op.out >= 0 ? tensor_ptr(op.out) : nullptr,
                             op.out2 >= 0 ? tensor_ptr(op.out2) : nullptr, d.has_aff ? P + d.s2 : nullptr, d.has_aff ? P + d.t2 : nullptr, s);
         timer.end(s, 5, 2.0 * op.macs * batch, op.bytes * batch);
         run(batch, s, 1);

@@ -52,6 +52,7 @@ class Net {
         size_t wt = 0, bias = 0, slope = 0, s2 = 0, t2 = 0;   // float offsets into params_
         bool has_slope = false, has_aff = false;
         size_t w27 = 0;                                       // stem layout [27][Cout] (op 0 only)
+        size_t wf = 0, bf = 0;                                // ... and with the u8 normalisation folded in (byte order, w / 128; adjusted bias)
         size_t dww = 0, dwb = 0;                              // fused depthwise front end (DWPW)
         size_t w36 = 0;                                       // Winograd F(4,3) weights U[36][rows][Cin]
         bool wino = false;                                    // eligible: 3x3 stride 1 pad 1, Cin >= 128

@@ -129,9 +129,11 @@ void launch_det_preprocess(const uint8_t* frames, long img_stride, int rows, int
 void launch_rec_preprocess(const uint8_t* crops, int n, int H, int W, float* out, hipStream_t s);
 // preprocess fused into the graph's first Conv 3x3 (Cin = 3): u8 BGR image -> [B,Ho,Wo,Cout] fp32.
 // w27 = [27][Cout] with k = (ky*3+kx)*3 + ci (ci in RGB order); act as fh::Act.
+// wf / biasf (optional): the same filter with the normalisation folded in, for the thread-per-pixel kernel: wf[(tap*3 + j)][Cout] =
+// w27[tap*3 + (2-j)] / 128 (j = byte of the BGR pixel), biasf = bias - 127.5/128 * sum_k w27[k].
 void launch_stem_conv_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int B, int inH, int inW, int stride,
-                         int Cout, const float* w27, const float* bias, const float* slope, int act, float* out1, float* out2,
-                         const float* s2, const float* t2, hipStream_t s);
+                         int Cout, const float* w27, const float* bias, const float* wf, const float* biasf, const float* slope, int act,
+                         float* out1, float* out2, const float* s2, const float* t2, hipStream_t s);
 
 struct DecodeArgs {
     const float* score[3];  // per stride [B, gh*gw*2]

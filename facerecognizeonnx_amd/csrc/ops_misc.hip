@@ -6,6 +6,10 @@
 // Also here: the first convolution fused with the u8 preprocess (stem_conv_u8_kernel).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+#include <stdexcept>
+
 #include "kernels.h"
 #include "plan.h"
 
@@ -358,9 +362,199 @@ __global__ __launch_bounds__(256) void stem_conv_u8_kernel(const uint8_t* __rest
     }
 }
 
+// ---- thread-per-pixel form ------------------------------------------------------------------------------------------------
+// One thread = one output pixel x ALL output channels.  The 27 input bytes of the pixel's 3x3 window are fetched as 3 aligned dwords
+// per image row straight from the u8 frame (neighbouring lanes overlap: L1 / L2 serve the re-reads, each byte leaves HBM once),
+// converted with v_cvt_f32_ubyteN, and multiplied by weights that live in SGPRs (every lane uses the same 27 x COUT weights: uniform
+// loads through the scalar cache, one SGPR operand per v_fmac).  No LDS, no barrier, ~60 VGPRs: 8 waves per SIMD hide the loads.
+// The normalisation (v - 127.5) / 128 is folded into the weights on the host: wf = w / 128 (a power of two: exact) in BYTE order
+// (B, G, R per pixel), biasf = bias - 127.5/128 * sum(w).  That only works where all nine taps are real image pixels, so this kernel
+// covers the INTERIOR of the output map; the thin frame of pixels whose window touches the zero padding, the letterbox canvas or the
+// first / last pixel of a row goes to stem_conv_border_kernel (literal arithmetic, per-tap bounds).
+typedef const unsigned __attribute__((address_space(1))) gmem_u32;
+// 16 FMAs of one tap: accumulator operands %0..%15, weights in SGPR bank A (s36..s51) or B (s52..s67), V = the tap's input value
+#define FH_STEM_FMA_A(V)                                                                                                                   \
+    "v_fmac_f32 %0, s36, " V "\n v_fmac_f32 %1, s37, " V "\n v_fmac_f32 %2, s38, " V "\n v_fmac_f32 %3, s39, " V "\n"                        \
+    "v_fmac_f32 %4, s40, " V "\n v_fmac_f32 %5, s41, " V "\n v_fmac_f32 %6, s42, " V "\n v_fmac_f32 %7, s43, " V "\n"                        \
+    "v_fmac_f32 %8, s44, " V "\n v_fmac_f32 %9, s45, " V "\n v_fmac_f32 %10, s46, " V "\n v_fmac_f32 %11, s47, " V "\n"                      \
+    "v_fmac_f32 %12, s48, " V "\n v_fmac_f32 %13, s49, " V "\n v_fmac_f32 %14, s50, " V "\n v_fmac_f32 %15, s51, " V "\n"
+#define FH_STEM_FMA_B(V)                                                                                                                   \
+    "v_fmac_f32 %0, s52, " V "\n v_fmac_f32 %1, s53, " V "\n v_fmac_f32 %2, s54, " V "\n v_fmac_f32 %3, s55, " V "\n"                        \
+    "v_fmac_f32 %4, s56, " V "\n v_fmac_f32 %5, s57, " V "\n v_fmac_f32 %6, s58, " V "\n v_fmac_f32 %7, s59, " V "\n"                        \
+    "v_fmac_f32 %8, s60, " V "\n v_fmac_f32 %9, s61, " V "\n v_fmac_f32 %10, s62, " V "\n v_fmac_f32 %11, s63, " V "\n"                      \
+    "v_fmac_f32 %12, s64, " V "\n v_fmac_f32 %13, s65, " V "\n v_fmac_f32 %14, s66, " V "\n v_fmac_f32 %15, s67, " V "\n"
+
+template <int STRIDE, int COUT>
+__global__ __launch_bounds__(256) void stem_conv_px_kernel(const uint8_t* __restrict__ src, long img_stride, int step, int Ho, int Wo, int x0,
+                                                           int y0, int nx, int ny, int B, const float* __restrict__ wf,
+                                                           const float* __restrict__ biasf, const float* __restrict__ slope, int act,
+                                                           float* __restrict__ out1, float* __restrict__ out2, const float* __restrict__ s2,
+                                                           const float* __restrict__ t2) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * ny * nx) return;
+    const int ox = x0 + idx % nx;
+    const int r0 = idx / nx;
+    const int oy = y0 + r0 % ny, b = r0 / ny;
+    const uint8_t* p = src + (size_t)b * img_stride + (size_t)(oy * STRIDE - 1) * step + (size_t)(ox * STRIDE - 1) * 3;
+    float v[27];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const unsigned long long a = (unsigned long long)(p + (size_t)r * step);
+        const unsigned sh = (unsigned)a & 3u;
+        const gmem_u32* q = (const gmem_u32*)(a - sh);                       // (explicit global address space: no flat loads)
+        const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
+        const unsigned n0 = __builtin_amdgcn_alignbyte(d1, d0, sh), n1 = __builtin_amdgcn_alignbyte(d2, d1, sh), n2 = d2 >> (8u * sh);
+        v[r * 9 + 0] = (float)(n0 & 255u); v[r * 9 + 1] = (float)((n0 >> 8) & 255u); v[r * 9 + 2] = (float)((n0 >> 16) & 255u); v[r * 9 + 3] = (float)(n0 >> 24);
+        v[r * 9 + 4] = (float)(n1 & 255u); v[r * 9 + 5] = (float)((n1 >> 8) & 255u); v[r * 9 + 6] = (float)((n1 >> 16) & 255u); v[r * 9 + 7] = (float)(n1 >> 24);
+        v[r * 9 + 8] = (float)(n2 & 255u);
+    }
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = biasf[c];
+    // Weights: every lane multiplies by the same 27 x COUT numbers, so they are fetched through the scalar cache into SGPRs and used
+    // as the scalar operand of v_fmac_f32.  Written as inline assembly, one block per image row (9 taps) and 16-channel group: left to
+    // the compiler, all 27 x COUT uniform loads are hoisted to the top of the kernel and ~400 SGPRs spill through v_writelane.  Inside
+    // a block two 16-SGPR banks alternate: the load of tap t+1 is issued before the 16 FMAs of tap t (SMEM returns out of order, so the
+    // only safe wait is lgkmcnt(0) — one per tap, behind 16 FMAs of cover; the other waves of the SIMD cover the rest).
+#pragma unroll
+    for (int g = 0; g < COUT / 16; ++g)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float* wrow = wf + (size_t)(r * 9) * COUT + g * 16;
+            float* a = acc + g * 16;
+            const float* x = v + r * 9;
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile(
+                "s_load_dwordx16 s[36:51], %25, 0\n"
+                "s_waitcnt lgkmcnt(0)\n"
+                "s_load_dwordx16 s[52:67], %25, %26\n" FH_STEM_FMA_A("%16")
+                "s_waitcnt lgkmcnt(0)\n"
+                "s_load_dwordx16 s[36:51], %25, %26*2\n" FH_STEM_FMA_B("%17")
+                "s_waitcnt lgkmcnt(0)\n"
+                "s_load_dwordx16 s[52:67], %25, %26*3\n" FH_STEM_FMA_A("%18")
+                "s_waitcnt lgkmcnt(0)\n"
+                "s_load_dwordx16 s[36:51], %25, %26*4\n" FH_STEM_FMA_B("%19")
+                "s_waitcnt lgkmcnt(0)\n"
+                "s_load_dwordx16 s[52:67], %25, %26*5\n" FH_STEM_FMA_A("%20")
+                "s_waitcnt lgkmcnt(0)\n"
+                "s_load_dwordx16 s[36:51], %25, %26*6\n" FH_STEM_FMA_B("%21")
+                "s_waitcnt lgkmcnt(0)\n"
+                "s_load_dwordx16 s[52:67], %25, %26*7\n" FH_STEM_FMA_A("%22")
+                "s_waitcnt lgkmcnt(0)\n"
+                "s_load_dwordx16 s[36:51], %25, %26*8\n" FH_STEM_FMA_B("%23")
+                "s_waitcnt lgkmcnt(0)\n" FH_STEM_FMA_A("%24")
+                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]),
+                  "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+                : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "s"(wrow), "n"(COUT * 4)
+                : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
+                  "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "memory");
+#else
+            (void)wrow; (void)a; (void)x;
+#endif
+        }
+    const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * COUT;
+#pragma unroll
+    for (int c4 = 0; c4 < COUT / 4; ++c4) {
+        v4f y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float u = acc[c4 * 4 + e];
+            if (act == 1) u = u > 0.f ? u : 0.f;
+            else if (act == 2) u = u >= 0.f ? u : u * slope[c4 * 4 + e];
+            else if (act == 3) u = 1.0f / (1.0f + expf(-u));
+            y[e] = u;
+        }
+        if (out1) *reinterpret_cast<v4f*>(out1 + o + c4 * 4) = y;
+        if (out2) {
+            v4f z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = y[e] * s2[c4 * 4 + e] + t2[c4 * 4 + e];
+            *reinterpret_cast<v4f*>(out2 + o + c4 * 4) = z;
+        }
+    }
+}
+
+// Frame of the output map around the interior [x0, x0+nx) x [y0, y0+ny): one thread per pixel and 4 channels, literal arithmetic
+// (conv zero padding outside the net input, u8 zeros on the letterbox canvas), w27 in the graph's RGB order.
+__global__ __launch_bounds__(256) void stem_conv_border_kernel(const uint8_t* __restrict__ src, long img_stride, int srcH, int srcW, int step, int inH,
+                                                               int inW, int stride, int Ho, int Wo, int Cout, int x0, int y0, int nx, int ny, int B,
+                                                               const float* __restrict__ w27, const float* __restrict__ bias,
+                                                               const float* __restrict__ slope, int act, float* __restrict__ out1,
+                                                               float* __restrict__ out2, const float* __restrict__ s2, const float* __restrict__ t2) {
+    const int G = Cout >> 2;
+    const int top = y0 * Wo, bottom = (Ho - y0 - ny) * Wo, side = Wo - nx;      // pixels above / below the interior rows, and per interior row beside it
+    const int per_img = top + bottom + ny * side;
+    const long total = (long)B * per_img * G;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(t % G);
+        const long pi = t / G;
+        const int b = (int)(pi / per_img);
+        int q = (int)(pi - (long)b * per_img), ox, oy;
+        if (q < top) { oy = q / Wo; ox = q - oy * Wo; }
+        else if (q < top + bottom) { q -= top; oy = y0 + ny + q / Wo; ox = q % Wo; }
+        else { q -= top + bottom; oy = y0 + q / side; const int j = q % side; ox = j < x0 ? j : j + nx; }
+        const uint8_t* img = src + (size_t)b * img_stride;
+        v4f acc = *reinterpret_cast<const v4f*>(bias + c4 * 4);
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy * stride - 1 + ky, ix = ox * stride - 1 + kx;
+                if ((unsigned)iy >= (unsigned)inH || (unsigned)ix >= (unsigned)inW) continue;     // conv zero padding
+                float vb = 0.f, vg = 0.f, vr = 0.f;                                                  // letterbox canvas = u8 zeros
+                if (iy < srcH && ix < srcW) {
+                    const uint8_t* px = img + (size_t)iy * step + (size_t)ix * 3;
+                    vb = (float)px[0]; vg = (float)px[1]; vr = (float)px[2];
+                }
+                const float x3[3] = {(vr - 127.5f) / 128.0f, (vg - 127.5f) / 128.0f, (vb - 127.5f) / 128.0f};
+                for (int ci = 0; ci < 3; ++ci) acc += *reinterpret_cast<const v4f*>(w27 + (size_t)((ky * 3 + kx) * 3 + ci) * Cout + c4 * 4) * x3[ci];
+            }
+        v4f sl = {0.f, 0.f, 0.f, 0.f};
+        if (slope) sl = *reinterpret_cast<const v4f*>(slope + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = act1(acc[e], act, sl[e]);
+        const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * Cout + c4 * 4;
+        if (out1) *reinterpret_cast<v4f*>(out1 + o) = acc;
+        if (out2) *reinterpret_cast<v4f*>(out2 + o) = acc * *reinterpret_cast<const v4f*>(s2 + c4 * 4) + *reinterpret_cast<const v4f*>(t2 + c4 * 4);
+    }
+}
+
+template <int STRIDE, int COUT>
+static void launch_stem_px(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int B, int inH, int inW, const float* w27,
+                           const float* bias, const float* wf, const float* biasf, const float* slope, int act, float* out1, float* out2,
+                           const float* s2, const float* t2, hipStream_t s) {
+    const int Ho = (inH + 2 - 3) / STRIDE + 1, Wo = (inW + 2 - 3) / STRIDE + 1;
+    // interior: every tap a real pixel of the pasted image, and each row's 12-byte window inside that row (not its first / last pixel)
+    int x0 = (2 + STRIDE - 1) / STRIDE, x1 = std::min(Wo, (srcW - 3) / STRIDE + 1), y0 = 1, y1 = std::min(Ho, (srcH - 2) / STRIDE + 1);
+    if (srcW < 4 || srcH < 3 || x1 <= x0 || y1 <= y0) { x0 = y0 = 0; x1 = y1 = 0; }
+    const int nx = x1 - x0, ny = y1 - y0;
+    if ((long)B * ny * nx >= (1L << 31)) throw std::runtime_error("stem conv: batch too large for the 32-bit pixel index (split the batch)");
+    if (nx > 0)
+        hipLaunchKernelGGL((stem_conv_px_kernel<STRIDE, COUT>), dim3((unsigned)(((long)B * ny * nx + 255) / 256)), dim3(256), 0, s, src, img_stride, step, Ho,
+                           Wo, x0, y0, nx, ny, B, wf, biasf, slope, act, out1, out2, s2, t2);
+    const long frame = (long)B * ((long)Ho * Wo - (long)ny * nx) * (COUT / 4);
+    if (frame > 0)
+        hipLaunchKernelGGL(stem_conv_border_kernel, dim3(grid_for(frame)), dim3(256), 0, s, src, img_stride, srcH, srcW, step, inH, inW, STRIDE, Ho, Wo,
+                           COUT, x0, y0, nx, ny, B, w27, bias, slope, act, out1, out2, s2, t2);
+}
+
+static bool stem_px_enabled() {                               // tuning hook (A/B): FACEHIP_STEM_PX=0 -> the LDS-tile kernel for every shape
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FACEHIP_STEM_PX"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+
 void launch_stem_conv_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int B, int inH, int inW, int stride,
-                         int Cout, const float* w27, const float* bias, const float* slope, int act, float* out1, float* out2,
-                         const float* s2, const float* t2, hipStream_t s) {
+                         int Cout, const float* w27, const float* bias, const float* wf, const float* biasf, const float* slope, int act,
+                         float* out1, float* out2, const float* s2, const float* t2, hipStream_t s) {
+    if (wf && stem_px_enabled()) {
+#define FH_STEM_PX(S, C) launch_stem_px<S, C>(src, img_stride, srcH, srcW, step, B, inH, inW, w27, bias, wf, biasf, slope, act, out1, out2, s2, t2, s); return
+        if (stride == 2 && Cout == 16) { FH_STEM_PX(2, 16); }
+        if (stride == 2 && Cout == 32) { FH_STEM_PX(2, 32); }
+        if (stride == 1 && Cout == 16) { FH_STEM_PX(1, 16); }
+        if (stride == 1 && Cout == 32) { FH_STEM_PX(1, 32); }
+        // (Cout = 64, IResNet's stem: 64 accumulators + 108 scalar loads per thread — measured 545 us against 176 us for the LDS-tile
+        //  kernel below at B = 128, whose 4-channels-per-thread layout also writes whole 256-byte pixel rows per wave)
+#undef FH_STEM_PX
+    }
     const int Ho = (inH + 2 - 3) / stride + 1, Wo = (inW + 2 - 3) / stride + 1;
     const int ntiles = B * ((Wo + STEM_TILE - 1) / STEM_TILE) * ((Ho + STEM_TILE - 1) / STEM_TILE);
     const int blocks = ntiles < 256 * 8 ? ntiles : 256 * 8;

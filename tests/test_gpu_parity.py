@@ -1103,3 +1103,22 @@ def test_frame_stream_equals_device_pipeline(models_dir):
     for (t, rf, ro, re_), (gf, go, ge) in zip(ref, got):
         assert len(gf) == t and gf.tobytes() == rf.tobytes() and np.array_equal(go, ro) and np.array_equal(ge, re_)
     st.close()
+
+
+def test_det500m_letterboxed_frame_heads_match_oracle():
+    """det_500m on a frame that is NOT 640x640 (500 x 375 -> scale 1.28, resized to 640 x 480, zero canvas below): the
+    thread-per-pixel stem kernel's interior / border split with a letterbox (u8 zeros, not conv padding) — all 9 heads vs oracle."""
+    from facerecognizeonnx_amd.synth import models
+    path = models.cached("det_500m_seed100.onnx", models.make_det_500m)
+    det = fa.FaceDetector(); odet = oracle.OracleDetector()
+    assert det.loadModel(path) and odet.loadModel(path)
+    for rows, cols in ((375, 500), (640, 401)):
+        img = util.frames_u8(1, rows, cols, seed=rows, smooth=True)
+        d = dev(img)
+        assert fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), 1, rows, cols, cols * 3, rows * cols * 3, 0) == 1
+        torch.cuda.synchronize()
+        got = _det_outputs(det, 1)
+        inp, scale = oracle.det_preprocess(img[0], 640, 640)
+        ref = odet.run_network(inp)
+        for i in range(9):
+            np.testing.assert_allclose(got[i][0], ref[i], rtol=1e-4, atol=1e-4, err_msg=f"{rows}x{cols} output {i}")
