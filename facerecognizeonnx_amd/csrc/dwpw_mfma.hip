@@ -16,8 +16,11 @@
 // layers are bandwidth-bound and >= 2 workgroups per CU overlap each other's phases.
 #include <hip/hip_runtime.h>
 
+#include <stdexcept>
+
 #include "kernels.h"
 #include "plan.h"
+#include "stem_fma.h"
 
 namespace fh {
 
@@ -32,6 +35,7 @@ __device__ __forceinline__ void dwpw_dma16(const float* src, v4f* dst) {
 #endif
 }
 
+typedef const unsigned __attribute__((address_space(1))) dwpw_gmem_u32;
 constexpr int DP_TH = 8, DP_TW = 16, DP_BM = DP_TH * DP_TW;            // 128 output pixels per tile
 constexpr int DP_HW = DP_TW + 2, DP_HALO = (DP_TH + 2) * DP_HW;         // 10 x 18 = 180 halo pixels
 
@@ -42,9 +46,10 @@ constexpr int DP_HW = DP_TW + 2, DP_HALO = (DP_TH + 2) * DP_HW;         // 10 x 
 // flight per CU) and the halo barrier disappears; it is the only form for DS == 2, whose 17 x 33 halo would not fit.
 // HC = 16-byte channel columns per pixel handled at a time: 8 (a 32-channel chunk), or 4 for layers with C <= 16 —
 // half the halo LDS, so more workgroups per CU, and no idle depthwise lanes.
-template <int BN, int WM, int WN, int DS, int HC, bool DIRECT>
-__global__ __launch_bounds__(256, DIRECT ? (BN * DS <= 64 ? 3 : 2) : HC == 4 ? 4 : 2) void dwpw_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_n) {
+template <int BN, int WM, int WN, int DS, int HC, bool DIRECT, bool STEM = false>
+__global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2) : HC == 4 ? 4 : 2) void dwpw_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_n) {
     static_assert(DS == 1 || DIRECT, "stride 2 needs the direct form");
+    static_assert(!STEM || (HC == 4 && !DIRECT && DP_HALO <= 256), "the fused stem produces a 16-channel halo, one pixel per thread");
     constexpr int BM = DP_BM;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int HALO_SLOTS = !DIRECT ? (DP_HALO * HC + 255) / 256 * 256 : 0;  // float4 slots, whole DMA passes
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(256, DIRECT ? (BN * DS <= 64 ? 3 : 2) : HC == 4 ? 4
     const int n = t / tiles_y;
     const int n0 = tile_n * BN;
     const int chunks = p.Kpad / 32;
-    const float* img = p.in + (size_t)n * p.H * p.W * C;                  // H x W = depthwise input, Ho x Wo = output grid
+    const float* img = STEM ? nullptr : p.in + (size_t)n * p.H * p.W * C;  // H x W = depthwise input, Ho x Wo = output grid
 
     // ---- halo loader: slot s = 256*j + tid covers halo pixel s>>3, 16-byte column s&7
     constexpr int HP = !DIRECT ? HALO_SLOTS / 256 : 1;
@@ -116,7 +121,78 @@ __global__ __launch_bounds__(256, DIRECT ? (BN * DS <= 64 ? 3 : 2) : HC == 4 ? 4
         const bool hvalid = c0 + hq * 4 < C;                               // 16-byte columns past C are never read: no DMA for them
         const int ksteps = min(4, (C - c0 + 7) >> 3);                      // 8-deep MFMA steps that hold real channels
         __syncthreads();                                                   // previous chunk: halo + fragments fully consumed
-        if (!DIRECT && hvalid) {
+        if (STEM) {
+            // halo pixel tid of the tile = one output pixel of the stem convolution, computed here from the u8 frame (3 aligned dwords per
+            // image row, weights in SGPRs: see stem_conv_px_kernel in ops_misc.hip); pixels outside the map are the depthwise zero padding
+            if (tid < DP_HALO) {
+                const int hy = tid / DP_HW, hx = tid - hy * DP_HW;
+                const int ay = ty0 + hy - 1, ax = tx0 + hx - 1;
+                float a16[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a16[c] = 0.f;
+                if ((unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W) {
+                    const int S = p.u8_stride;
+                    const int iy0 = ay * S - 1, ix0 = ax * S - 1;
+                    const uint8_t* frame = p.u8_src + (size_t)n * p.u8_img_stride;
+                    float v[27];
+                    if (iy0 >= 0 && iy0 + 2 < p.u8_srcH && ix0 >= 1 && ix0 + 2 <= p.u8_srcW - 2) {
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            const unsigned long long a = (unsigned long long)(frame + (size_t)(iy0 + r) * p.u8_step + (size_t)ix0 * 3);
+                            const unsigned sh = (unsigned)a & 3u;
+                            const dwpw_gmem_u32* q = (const dwpw_gmem_u32*)(a - sh);
+                            const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
+                            const unsigned n0 = __builtin_amdgcn_alignbyte(d1, d0, sh), n1 = __builtin_amdgcn_alignbyte(d2, d1, sh), n2 = d2 >> (8u * sh);
+                            v[r * 9 + 0] = (float)(n0 & 255u); v[r * 9 + 1] = (float)((n0 >> 8) & 255u); v[r * 9 + 2] = (float)((n0 >> 16) & 255u); v[r * 9 + 3] = (float)(n0 >> 24);
+                            v[r * 9 + 4] = (float)(n1 & 255u); v[r * 9 + 5] = (float)((n1 >> 8) & 255u); v[r * 9 + 6] = (float)((n1 >> 16) & 255u); v[r * 9 + 7] = (float)(n1 >> 24);
+                            v[r * 9 + 8] = (float)(n2 & 255u);
+                        }
+                    } else {
+                        // window touches the frame's border: per tap — outside the net input = conv zero padding (127.5 cancels against the
+                        // folded bias), inside it but outside the pasted image = letterbox canvas (u8 0)
+#pragma unroll
+                        for (int r = 0; r < 3; ++r)
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                const int iy = iy0 + r, ix = ix0 + c;
+                                float b0 = 127.5f, b1 = 127.5f, b2 = 127.5f;
+                                if ((unsigned)iy < (unsigned)p.u8_inH && (unsigned)ix < (unsigned)p.u8_inW) {
+                                    b0 = b1 = b2 = 0.f;
+                                    if (iy < p.u8_srcH && ix < p.u8_srcW) {
+                                        const uint8_t* px = frame + (size_t)iy * p.u8_step + (size_t)ix * 3;
+                                        b0 = (float)px[0]; b1 = (float)px[1]; b2 = (float)px[2];
+                                    }
+                                }
+                                v[r * 9 + c * 3 + 0] = b0; v[r * 9 + c * 3 + 1] = b1; v[r * 9 + c * 3 + 2] = b2;
+                            }
+                    }
+                    fh_v2f a2[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) a2[i] = fh_v2f{p.stem_bf[2 * i], p.stem_bf[2 * i + 1]};
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float* wrow = p.stem_wf + (size_t)(r * 9) * 16;
+                        fh_v2f xp[5];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) xp[i] = fh_v2f{v[r * 9 + 2 * i], v[r * 9 + 2 * i + 1]};
+                        xp[4] = fh_v2f{v[r * 9 + 8], 0.f};
+#if defined(__HIP_DEVICE_COMPILE__)
+                        FH_STEM_ROW_FMA(a2, xp, wrow, 64);
+#else
+                        (void)wrow; (void)xp;
+#endif
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { a16[2 * i] = a2[i][0]; a16[2 * i + 1] = a2[i][1]; }
+                    if (p.stem_act == (int)Act::RELU) {
+#pragma unroll
+                        for (int c = 0; c < 16; ++c) a16[c] = a16[c] > 0.f ? a16[c] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) halo[tid * 4 + q] = v4f{a16[4 * q], a16[4 * q + 1], a16[4 * q + 2], a16[4 * q + 3]};
+            }
+        } else if (!DIRECT && hvalid) {
 #pragma unroll
             for (int j = 0; j < HP; ++j) {
                 const float* src = h_off[j] >= 0 ? img + h_off[j] + c0 : p.zeros;
@@ -258,7 +334,12 @@ static void launch_dwpw_cfg(const ConvArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)(a.B * tiles_y * tiles_x * tiles_n));
     // (the direct form was measured for stride 1 too: 15-20 % slower than the LDS halo on every SCRFD layer —
     //  L1 traffic of the 4.5-6x re-reads costs more than the extra loads in flight gain)
-    if (a.dw_stride == 2) hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN, 2, 8, true>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
+    if (a.u8_src) {
+        if (a.Cin != 16 || a.dw_stride != 1 || BN > 64) throw std::runtime_error("dwpw: the fused stem needs 16 channels, stride 1 and Cout <= 64");
+        hipLaunchKernelGGL((dwpw_kernel<(BN <= 64 ? BN : 64), (BN <= 64 ? WM : 2), (BN <= 64 ? WN : 2), 1, 4, false, true>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
+    } else if (a.dw_stride == 2 && a.Cin <= 16 && BN <= 64)     // 16 channels = 4 float4 columns: every depthwise lane busy, 2-row strips (fewer registers)
+        hipLaunchKernelGGL((dwpw_kernel<(BN <= 64 ? BN : 64), (BN <= 64 ? WM : 2), (BN <= 64 ? WN : 2), 2, 4, true>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
+    else if (a.dw_stride == 2) hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN, 2, 8, true>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
     else if (a.Cin <= 16 && BN <= 64) hipLaunchKernelGGL((dwpw_kernel<(BN <= 64 ? BN : 64), (BN <= 64 ? WM : 2), (BN <= 64 ? WN : 2), 1, 4, false>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
     else hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN, 1, 8, false>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
 }

@@ -168,6 +168,15 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
             dev_[0].bf = push(bf.data(), bf.size());
         }
     }
+    if (stem_ok_ && plan_.ops.size() > 1) {   // can the stem also be pulled into the depthwise -> pointwise block that consumes it?
+        const POp& st = plan_.ops[0];
+        const POp& nx = plan_.ops[1];
+        int uses = 0;
+        for (const auto& o : plan_.ops) for (int x : {o.in, o.in2, o.res}) if (x == st.out) ++uses;
+        for (const auto& o : plan_.outputs) if (o.tensor == st.out) ++uses;
+        front_ok_ = st.Cout == 16 && st.out >= 0 && st.out2 < 0 && (st.act == Act::NONE || st.act == Act::RELU) && nx.kind == OpKind::DWPW &&
+                    nx.in == st.out && uses == 1 && nx.dw_stride == 1 && nx.Cin == 16 && nx.Cout <= 64;
+    }
     params_.ensure(std::max<size_t>(host.size(), 64) * sizeof(float));
     FH_HIP(hipMemcpy(params_.p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     // host copies of the weights are no longer needed
@@ -194,6 +203,27 @@ void Net::reserve(int max_batch) {
 void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int batch, hipStream_t s) {
     if (batch <= 0) return;
     if (batch > cap_) throw std::runtime_error("Net::run_u8: batch exceeds reserved capacity");
+    if (stem_ok_ && fuse_stem && front_ok_ && fuse_front) {
+        // stem conv -> depthwise 3x3 -> pointwise 1x1 in ONE kernel: the stem's 16-channel map (the largest tensor of SCRFD) is never written
+        const POp& st = plan_.ops[0];
+        const POp& op = plan_.ops[1];
+        const DevOp& d0 = dev_[0];
+        const DevOp& d = dev_[1];
+        const float* P = params_.as<float>();
+        ConvArgs a{};
+        a.wt = P + d.wt; a.bias = P + d.bias;
+        a.out1 = tensor_ptr(op.out);
+        a.dw_w = P + d.dww; a.dw_b = P + d.dwb; a.dw_act = (int)op.dw_act; a.dw_stride = op.dw_stride;
+        a.B = batch; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
+        a.ks = 1; a.stride = 1; a.pad = 0; a.Kpad = d.Kpad; a.act = (int)op.act;
+        a.u8_src = src; a.u8_img_stride = img_stride; a.u8_step = step; a.u8_srcH = srcH; a.u8_srcW = srcW; a.u8_inH = plan_.inH; a.u8_inW = plan_.inW;
+        a.u8_stride = st.stride; a.stem_act = (int)st.act; a.stem_wf = P + d0.wf; a.stem_bf = P + d0.bf;
+        a.t_flops = 2.0 * (st.macs + op.macs) * batch;
+        a.t_bytes = ((double)srcH * srcW * 3 + (double)op.Ho * op.Wo * op.Cout * 4) * batch;        // u8 frame in, pointwise map out
+        launch_dwpw(a, s);
+        run(batch, s, 2);
+        return;
+    }
     if (stem_ok_ && fuse_stem) {
         const POp& op = plan_.ops[0];
         const DevOp& d = dev_[0];

@@ -38,6 +38,7 @@ class Net {
     // srcH x srcW = pasted image (<= net input; the remainder is the zero letterbox canvas)
     void run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int batch, hipStream_t s);
     bool fuse_stem = true;                                // tuning / test hook: keep the preprocessed input tensor
+    bool fuse_front = true;                               // tuning / test hook: stem conv inside the first depthwise -> pointwise kernel
     const Plan& plan() const { return plan_; }
     int in_h() const { return plan_.inH; }
     int in_w() const { return plan_.inW; }
@@ -69,6 +70,7 @@ class Net {
     size_t wino_elems_ = 0;                                   // per image: 36 * tiles * max(Cin, Cout) of the largest Winograd op
     int cap_ = 0;
     bool stem_ok_ = false;
+    bool front_ok_ = false;                                   // ops 0 + 1 = stem conv (16 channels) -> DW+PW: one kernel
 };
 
 class Detector {

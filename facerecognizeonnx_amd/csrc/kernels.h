@@ -58,6 +58,14 @@ struct ConvArgs {
     const float* dw_b;
     int dw_act;
     int dw_stride;          // 1 | 2
+    // fused u8 stem in FRONT of the depthwise part (launch_dwpw with u8_src != null): `in` is not read — the workgroup computes the
+    // stem convolution (3x3, 3 -> 16 channels, stride u8_stride, preprocess folded into stem_wf / stem_bf as for launch_stem_conv_u8)
+    // for its halo pixels straight from the BGR u8 frames.  H x W = the stem's output grid = the depthwise input.
+    const uint8_t* u8_src;
+    long u8_img_stride;
+    int u8_step, u8_srcH, u8_srcW, u8_inH, u8_inW, u8_stride, stem_act;
+    const float* stem_wf;
+    const float* stem_bf;
     int n_outs;             // > 0: merged sibling convs — channels [oc0[g], oc0[g+1]) go to outs[g] with act oact[g]
     float* outs[3];
     int oc0[4];

@@ -12,6 +12,7 @@
 
 #include "kernels.h"
 #include "plan.h"
+#include "stem_fma.h"
 
 namespace fh {
 
@@ -372,18 +373,6 @@ __global__ __launch_bounds__(256) void stem_conv_u8_kernel(const uint8_t* __rest
 // covers the INTERIOR of the output map; the thin frame of pixels whose window touches the zero padding, the letterbox canvas or the
 // first / last pixel of a row goes to stem_conv_border_kernel (literal arithmetic, per-tap bounds).
 typedef const unsigned __attribute__((address_space(1))) gmem_u32;
-// 16 FMAs of one tap: accumulator operands %0..%15, weights in SGPR bank A (s36..s51) or B (s52..s67), V = the tap's input value
-#define FH_STEM_FMA_A(V)                                                                                                                   \
-    "v_fmac_f32 %0, s36, " V "\n v_fmac_f32 %1, s37, " V "\n v_fmac_f32 %2, s38, " V "\n v_fmac_f32 %3, s39, " V "\n"                        \
-    "v_fmac_f32 %4, s40, " V "\n v_fmac_f32 %5, s41, " V "\n v_fmac_f32 %6, s42, " V "\n v_fmac_f32 %7, s43, " V "\n"                        \
-    "v_fmac_f32 %8, s44, " V "\n v_fmac_f32 %9, s45, " V "\n v_fmac_f32 %10, s46, " V "\n v_fmac_f32 %11, s47, " V "\n"                      \
-    "v_fmac_f32 %12, s48, " V "\n v_fmac_f32 %13, s49, " V "\n v_fmac_f32 %14, s50, " V "\n v_fmac_f32 %15, s51, " V "\n"
-#define FH_STEM_FMA_B(V)                                                                                                                   \
-    "v_fmac_f32 %0, s52, " V "\n v_fmac_f32 %1, s53, " V "\n v_fmac_f32 %2, s54, " V "\n v_fmac_f32 %3, s55, " V "\n"                        \
-    "v_fmac_f32 %4, s56, " V "\n v_fmac_f32 %5, s57, " V "\n v_fmac_f32 %6, s58, " V "\n v_fmac_f32 %7, s59, " V "\n"                        \
-    "v_fmac_f32 %8, s60, " V "\n v_fmac_f32 %9, s61, " V "\n v_fmac_f32 %10, s62, " V "\n v_fmac_f32 %11, s63, " V "\n"                      \
-    "v_fmac_f32 %12, s64, " V "\n v_fmac_f32 %13, s65, " V "\n v_fmac_f32 %14, s66, " V "\n v_fmac_f32 %15, s67, " V "\n"
-
 template <int STRIDE, int COUT>
 __global__ __launch_bounds__(256) void stem_conv_px_kernel(const uint8_t* __restrict__ src, long img_stride, int step, int Ho, int Wo, int x0,
                                                            int y0, int nx, int ny, int B, const float* __restrict__ wf,
@@ -411,47 +400,28 @@ __global__ __launch_bounds__(256) void stem_conv_px_kernel(const uint8_t* __rest
     float acc[COUT];
 #pragma unroll
     for (int c = 0; c < COUT; ++c) acc[c] = biasf[c];
-    // Weights: every lane multiplies by the same 27 x COUT numbers, so they are fetched through the scalar cache into SGPRs and used
-    // as the scalar operand of v_fmac_f32.  Written as inline assembly, one block per image row (9 taps) and 16-channel group: left to
-    // the compiler, all 27 x COUT uniform loads are hoisted to the top of the kernel and ~400 SGPRs spill through v_writelane.  Inside
-    // a block two 16-SGPR banks alternate: the load of tap t+1 is issued before the 16 FMAs of tap t (SMEM returns out of order, so the
-    // only safe wait is lgkmcnt(0) — one per tap, behind 16 FMAs of cover; the other waves of the SIMD cover the rest).
+    // weights in SGPRs, packed FMAs: see stem_fma.h.  One asm block per image row (9 taps) and 16-channel group.
 #pragma unroll
-    for (int g = 0; g < COUT / 16; ++g)
+    for (int g = 0; g < COUT / 16; ++g) {
+        fh_v2f a2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a2[i] = fh_v2f{acc[g * 16 + 2 * i], acc[g * 16 + 2 * i + 1]};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const float* wrow = wf + (size_t)(r * 9) * COUT + g * 16;
-            float* a = acc + g * 16;
-            const float* x = v + r * 9;
+            fh_v2f xp[5];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xp[i] = fh_v2f{v[r * 9 + 2 * i], v[r * 9 + 2 * i + 1]};
+            xp[4] = fh_v2f{v[r * 9 + 8], 0.f};
 #if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile(
-                "s_load_dwordx16 s[36:51], %25, 0\n"
-                "s_waitcnt lgkmcnt(0)\n"
-                "s_load_dwordx16 s[52:67], %25, %26\n" FH_STEM_FMA_A("%16")
-                "s_waitcnt lgkmcnt(0)\n"
-                "s_load_dwordx16 s[36:51], %25, %26*2\n" FH_STEM_FMA_B("%17")
-                "s_waitcnt lgkmcnt(0)\n"
-                "s_load_dwordx16 s[52:67], %25, %26*3\n" FH_STEM_FMA_A("%18")
-                "s_waitcnt lgkmcnt(0)\n"
-                "s_load_dwordx16 s[36:51], %25, %26*4\n" FH_STEM_FMA_B("%19")
-                "s_waitcnt lgkmcnt(0)\n"
-                "s_load_dwordx16 s[52:67], %25, %26*5\n" FH_STEM_FMA_A("%20")
-                "s_waitcnt lgkmcnt(0)\n"
-                "s_load_dwordx16 s[36:51], %25, %26*6\n" FH_STEM_FMA_B("%21")
-                "s_waitcnt lgkmcnt(0)\n"
-                "s_load_dwordx16 s[52:67], %25, %26*7\n" FH_STEM_FMA_A("%22")
-                "s_waitcnt lgkmcnt(0)\n"
-                "s_load_dwordx16 s[36:51], %25, %26*8\n" FH_STEM_FMA_B("%23")
-                "s_waitcnt lgkmcnt(0)\n" FH_STEM_FMA_A("%24")
-                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]),
-                  "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
-                : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "s"(wrow), "n"(COUT * 4)
-                : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53",
-                  "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "memory");
+            FH_STEM_ROW_FMA(a2, xp, wrow, COUT * 4);
 #else
-            (void)wrow; (void)a; (void)x;
+            (void)wrow; (void)xp;
 #endif
         }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { acc[g * 16 + 2 * i] = a2[i][0]; acc[g * 16 + 2 * i + 1] = a2[i][1]; }
+    }
     const size_t o = (((size_t)b * Ho + oy) * Wo + ox) * COUT;
 #pragma unroll
     for (int c4 = 0; c4 < COUT / 4; ++c4) {

@@ -195,6 +195,9 @@ FH_API int fh_rec_set_cus(fh_rec* r, int cus);
  * never materialised; off: separate preprocess kernel (needed for fh_det_input_dev). */
 FH_API int fh_det_set_fused_stem(fh_det* d, int on);
 FH_API int fh_rec_set_fused_stem(fh_rec* r, int on);
+/* on (default): when the graph opens with conv 3x3 (16 channels) -> depthwise 3x3 -> pointwise 1x1 (SCRFD's first block), the stem
+ * is computed inside the depthwise -> pointwise kernel and its output map never reaches memory; off: separate kernels. */
+FH_API int fh_det_set_fused_front(fh_det* d, int on);
 
 /* ---- image files -> BGR u8, replaces cv::imread(path) (reference src/main.cpp:42,71-72,140-141; OpenCV's default
  * IMREAD_COLOR: 8-bit BGR, alpha dropped, grey replicated, JPEG EXIF orientation applied).  Host code.  JPEG

@@ -1122,3 +1122,25 @@ def test_det500m_letterboxed_frame_heads_match_oracle():
         ref = odet.run_network(inp)
         for i in range(9):
             np.testing.assert_allclose(got[i][0], ref[i], rtol=1e-4, atol=1e-4, err_msg=f"{rows}x{cols} output {i}")
+
+
+def test_fused_front_equals_separate_kernels():
+    """Stem conv computed inside the first depthwise -> pointwise kernel (SCRFD's opening block) vs the three-kernel form: same heads
+    up to fp32 summation order, on a full frame, a letterboxed frame and a frame with a padded row pitch."""
+    from facerecognizeonnx_amd.synth import models
+    path = models.cached("det_500m_seed100.onnx", models.make_det_500m)
+    det = fa.FaceDetector()
+    assert det.loadModel(path)
+    assert "0 CONV k3s2 640x640x4 -> 320x320x16+relu" in fa.plan_describe(path, 640, 640) and "1 DW+PW k1s1 320x320x16" in fa.plan_describe(path, 640, 640)
+    for rows, cols, pitch in ((640, 640, 1920), (333, 640, 1920), (640, 250, 250 * 3 + 5)):
+        img = np.zeros((2, rows, pitch), np.uint8)
+        img[:, :, :cols * 3] = util.frames_u8(2, rows, cols, seed=rows + cols).reshape(2, rows, cols * 3)
+        d = dev(img)
+        outs = []
+        for on in (1, 0):
+            assert fa.lib().fh_det_set_fused_front(det.handle, on) == 0
+            assert fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), 2, rows, cols, pitch, rows * pitch, 0) == 2
+            torch.cuda.synchronize()
+            outs.append(_det_outputs(det, 2))
+        for a, b in zip(*outs):
+            np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5, err_msg=f"{rows}x{cols} pitch {pitch}")
