@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=128, help="frames per batch per GPU")
     ap.add_argument("--faces-per-frame", type=int, default=1)
-    ap.add_argument("--workload", default="e2e", choices=["e2e", "embed", "detect"])
+    ap.add_argument("--workload", default="e2e", choices=["e2e", "embed", "detect", "match"])
+    ap.add_argument("--queries", type=int, default=64, help="--workload match: query embeddings per step (config C4: one per frame of a 64-frame batch)")
     ap.add_argument("--crops", type=int, default=256, help="--workload embed: pre-aligned crops per batch (config 2)")
     ap.add_argument("--score-thr", type=float, default=0.5)
     ap.add_argument("--nms-thr", type=float, default=0.4)
@@ -172,6 +173,73 @@ def cpu_baseline(det_path, rec_path, frames_np, args, threads=None):
             "sample": what + f" ({dt:.1f} s, CPU oracle = restatement of the reference, not ONNX Runtime)"}
 
 
+def bench_match(args, rank, world, local, dist, cdev, fa, torch):
+    """1:N compareFaces leg (config C4's last stage / C5's sharded form): Q query embeddings against a gallery of G rows
+    (row-sharded over the ranks), top-k.  One step = one query batch.  The scan kernel reads every gallery row once, so it is
+    priced against HBM with G x dim x 4 algorithmic bytes; its 2*Q*G*dim FLOP on the f32 matrix cores are reported beside it."""
+    from facerecognizeonnx_amd import distributed as fd
+    G = args.gallery or 1_000_000
+    Q, k, dim = args.queries, args.topk, 512
+    gb, ge = fd.gallery_shard_base(G, rank, world)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(4 + rank)
+    gal = torch.randn((ge - gb, dim), device="cuda", generator=gen)
+    gal /= gal.norm(dim=1, keepdim=True)
+    gallery = fa.Gallery(dim)
+    gallery.upload(gal.data_ptr(), ge - gb, True, gb)
+    del gal
+    q = torch.randn((Q, dim), device="cuda", generator=gen); q /= q.norm(dim=1, keepdim=True)
+    sc = torch.zeros((Q, k), device="cuda"); ix = torch.zeros((Q, k), dtype=torch.int32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        gallery.topk_dev(q.data_ptr(), Q, k, sc.data_ptr(), ix.data_ptr(), stream)
+        if world > 1:
+            fd.allgather_topk(sc, ix, k, comm_device=cdev)
+        return Q
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    units = 0
+    for _ in range(args.steps):
+        units += step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    # kernel-level: HIP events on the stream the scan runs on, around the library call only (scan + list merge)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = max(5, min(args.steps, 20))
+    e0.record()
+    for _ in range(reps):
+        gallery.topk_dev(q.data_ptr(), Q, k, sc.data_ptr(), ix.data_ptr(), stream)
+    e1.record(); torch.cuda.synchronize()
+    kms = e0.elapsed_time(e1) / reps
+    max_dt, tot = dt, float(units)
+    if dist is not None:
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        max_dt = float(t.item())                   # every rank answers the SAME Q queries against its shard: units are not summed
+    if rank == 0:
+        rows_local = ge - gb
+        gbs = rows_local * dim * 4 / (kms * 1e-3) / 1e9
+        tf = 2.0 * Q * rows_local * dim / (kms * 1e-3) / 1e12
+        out = {"metric": "queries/sec 1:N compareFaces top-k against a 512-d gallery", "value": tot / max_dt, "unit": "queries/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * max_dt / max(args.steps, 1), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"C4 match stage: {Q} L2-normalised 512-d queries vs {G} gallery rows ({rows_local} on this rank), top-{k} "
+                                      f"by (dot+1)/2", "gallery_rows": G, "queries": Q, "topk": k,
+                          "parallelism": f"gallery row-sharded x{world}" + (", one all-gather of per-rank top-k + kernel merge" if world > 1 else "")},
+               "roofline": {"bound": "hbm", "kernel": "gallery_topk_kernel (+ topk_merge_kernel)", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                            "frac": gbs / 8000.0, "traffic": None, "avg_launch_us": 1e3 * kms,
+                            "algorithmic_mbytes_per_launch": rows_local * dim * 4 / 1e6, "mfma_tflops": tf, "mfma_frac": tf / F32_MFMA_PEAK_TFLOPS}}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -205,6 +273,8 @@ def main():
     L = fa.lib()
     fa._lib.check(L.fh_init(local), "fh_init")
 
+    if args.workload == "match":                                       # no networks involved: gallery scan only
+        return bench_match(args, rank, world, local, dist, cdev, fa, torch)
     # synthetic models (seeded; the genuine .onnx files are not available offline)
     if local == 0:
         det_path = models.cached("det_500m_seed100.onnx", models.make_det_500m)

@@ -505,6 +505,7 @@ static int num_cus() {
     }
     return g_num_cus;
 }
+int conv_num_cus() { return num_cus(); }
 const float* conv_zero_line() {                      // 8 KiB of zeros: a padded tap streams up to Cin*4 bytes from it
     if (!g_zeros) {
         void* p = nullptr;

@@ -504,32 +504,19 @@ void Gallery::label_dev(const float* q, int Q, float thr, int* out_label, float*
 
 void Gallery::topk_dev(const float* q, int Q, int k, float* out_score, int* out_idx, hipStream_t s) {
     if (Q <= 0 || Q > 256 || k <= 0 || k > 16) throw std::runtime_error("gallery: need 0 < Q <= 256 and 0 < k <= 16");
-    const long kSlab = 1L << 20;
-    const int nsub = 256 / Q;
-    const int wrows = conv_wt_rows(Q);
-    qpack_.ensure((size_t)wrows * dim_ * sizeof(float));
-    FH_HIP(hipMemsetAsync(qpack_.p, 0, (size_t)wrows * dim_ * sizeof(float), s));
+    if (dim_ % 32) throw std::runtime_error("gallery: dim must be a multiple of 32");
+    // queries as the GEMM's N operand: whole 64-row tiles, zero rows behind Q (only that tail is cleared)
+    const int qrows = (Q + 63) / 64 * 64;
+    qpack_.ensure((size_t)qrows * dim_ * sizeof(float));
+    if (qrows > Q) FH_HIP(hipMemsetAsync(qpack_.as<float>() + (size_t)Q * dim_, 0, (size_t)(qrows - Q) * dim_ * sizeof(float), s));
     FH_HIP(hipMemcpyAsync(qpack_.p, q, (size_t)Q * dim_ * sizeof(float), hipMemcpyDeviceToDevice, s));
-    dots_.ensure((size_t)std::min(kSlab, std::max(n_, 1L)) * Q * sizeof(float));
-    int parts_total = 0;
-    for (long r0 = 0; r0 < n_; r0 += kSlab) parts_total += gallery_blocks(std::min(kSlab, n_ - r0)) * nsub;
-    ps_.ensure((size_t)std::max(parts_total, 1) * Q * k * sizeof(float));
-    pi_.ensure((size_t)std::max(parts_total, 1) * Q * k * sizeof(int));
-    int part = 0;
-    for (long r0 = 0; r0 < n_; r0 += kSlab) {
-        const long g = std::min(kSlab, n_ - r0);
-        ConvArgs a{};
-        a.in = rows_.as<float>() + (size_t)r0 * dim_;
-        a.wt = qpack_.as<float>();
-        a.out1 = dots_.as<float>();
-        a.B = (int)g; a.H = a.W = a.Ho = a.Wo = 1; a.Cin = dim_; a.Cout = Q; a.ks = 1; a.stride = 1; a.pad = 0;
-        a.Kpad = dim_;
-        launch_conv(a, -1, s);
-        launch_topk_partial(dots_.as<float>(), g, Q, k, ps_.as<float>() + (size_t)part * Q * k, pi_.as<int>() + (size_t)part * Q * k,
-                            base_ + r0, s);
-        part += gallery_blocks(g) * nsub;
-    }
-    launch_topk_merge(ps_.as<float>(), pi_.as<int>(), parts_total, Q, k, out_score, out_idx, s);
+    int tpp = 0;
+    const int parts = n_ > 0 ? gallery_parts(n_, Q, &tpp) : 0;
+    ps_.ensure((size_t)std::max(parts, 1) * Q * k * sizeof(float));
+    pi_.ensure((size_t)std::max(parts, 1) * Q * k * sizeof(int));
+    // ONE pass over the gallery: dot products stay in the MFMA accumulators, per-workgroup top-k lists come out (gallery.hip)
+    launch_gallery_topk(rows_.as<float>(), n_, dim_, qpack_.as<float>(), Q, k, base_, ps_.as<float>(), pi_.as<int>(), s);
+    launch_topk_merge(ps_.as<float>(), pi_.as<int>(), parts, Q, k, out_score, out_idx, s);
     FH_HIP(hipGetLastError());
 }
 

@@ -461,38 +461,11 @@ void launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_
 
 // ------------------------------------------------------------------------------------------
 // FaceRecognizer::compareFaces generalised to a gallery (src/face_recognizer.cpp:320-334):
-// mapped score (dot + 1) / 2, ranked (score desc, gallery index asc).  The dot products come
-// from the MFMA GEMM (gallery rows x queries); here: per-slab partial top-k, then a merge.
+// mapped score (dot + 1) / 2, ranked (score desc, gallery index asc).  The scan itself is
+// gallery.hip (one pass, per-workgroup top-k lists); here: the merge of those lists — also the
+// merge step of a row-sharded gallery (fh_topk_merge_dev).
 // ------------------------------------------------------------------------------------------
-constexpr int TOPK_MAX = 16;
-constexpr int GAL_ROWS_PER_BLOCK = 4096;
-
-int gallery_blocks(long G) { return (int)((G + GAL_ROWS_PER_BLOCK - 1) / GAL_ROWS_PER_BLOCK); }
-
 __device__ __forceinline__ bool better(float s1, int i1, float s2, int i2) { return s1 > s2 || (s1 == s2 && i1 < i2); }
-
-// dots: [G][Q]; thread (sub, q) scans rows sub, sub+nsub, ... of the block's slab
-__global__ __launch_bounds__(256) void topk_partial_kernel(const float* __restrict__ dots, long G, int Q, int k, float* __restrict__ ps,
-                                                           int* __restrict__ pi, long idx_base) {
-    const int nsub = 256 / Q;
-    const int q = threadIdx.x % Q, sub = threadIdx.x / Q;
-    if (sub >= nsub) return;
-    const long r0 = (long)blockIdx.x * GAL_ROWS_PER_BLOCK;
-    const long r1 = r0 + GAL_ROWS_PER_BLOCK < G ? r0 + GAL_ROWS_PER_BLOCK : G;
-    float bs[TOPK_MAX]; int bi[TOPK_MAX];
-    int cnt = 0;
-    for (long r = r0 + sub; r < r1; r += nsub) {
-        const float sc = (dots[(size_t)r * Q + q] + 1.0f) / 2.0f;
-        const int gi = (int)(idx_base + r);
-        if (cnt < k || better(sc, gi, bs[cnt - 1], bi[cnt - 1])) {
-            int p = cnt < k ? cnt++ : k - 1;
-            while (p > 0 && better(sc, gi, bs[p - 1], bi[p - 1])) { bs[p] = bs[p - 1]; bi[p] = bi[p - 1]; --p; }
-            bs[p] = sc; bi[p] = gi;
-        }
-    }
-    const size_t o = (((size_t)blockIdx.x * nsub + sub) * Q + q) * k;
-    for (int p = 0; p < k; ++p) { ps[o + p] = p < cnt ? bs[p] : -1.0f; pi[o + p] = p < cnt ? bi[p] : -1; }
-}
 
 // one workgroup per query: k rounds of "best entry that comes after the previous pick"
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ ps, const int* __restrict__ pi, int nparts, int Q, int k,
@@ -526,10 +499,6 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
         __syncthreads();
         if (last_i == 0x7fffffff) { last_s = -3.0f; }   // nothing left: later rounds find nothing either
     }
-}
-
-void launch_topk_partial(const float* dots, long G, int Q, int k, float* part_score, int* part_idx, long idx_base, hipStream_t s) {
-    hipLaunchKernelGGL(topk_partial_kernel, dim3(gallery_blocks(G)), dim3(256), 0, s, dots, G, Q, k, part_score, part_idx, idx_base);
 }
 
 // Match / Unknown decision of the reference's webcam loop (src/main.cpp:229-233): a query is labelled with its best

@@ -88,6 +88,7 @@ void launch_conv(const ConvArgs& a, int cfg, hipStream_t s);
 int conv_pick_cfg(long M, int Cout);
 void conv_workspace_init(float* ws);          // zero the counter words of a freshly allocated stream-K workspace
 const float* conv_zero_line();                // 8 KiB of device zeros (target of padded / dead loads)
+int conv_num_cus();                           // compute units of the current device
 // depthwise 3x3 stride 1 (+bias +act) fused with the 1x1 conv that consumes it (dwpw_mfma.hip)
 void launch_dwpw(const ConvArgs& a, hipStream_t s);
 // Winograd F(4x4,3x3) form of a 3x3 stride-1 pad-1 convolution (winograd.hip): a = the convolution's arguments,
@@ -173,15 +174,15 @@ void launch_resize_u8c3(const uint8_t* src, long src_stride, int sh, int sw, int
 // FaceRecognizer::normalize (src/face_recognizer.cpp:306-318), one wave per row
 void launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_t s);
 
-// compareFaces generalised to 1:N (src/face_recognizer.cpp:320-334): top-k of (dot+1)/2 ranked
-// (score desc, gallery index asc).  dots = [G][Q] raw dot products from launch_conv (gallery rows
-// as GEMM-M, queries as GEMM-N); partial lists [gallery_blocks(G)*(256/Q)][Q][k] then one merge.
-void launch_topk_partial(const float* dots, long G, int Q, int k, float* part_score, int* part_idx, long idx_base,
+// compareFaces generalised to 1:N (src/face_recognizer.cpp:320-334): top-k of (dot+1)/2 ranked (score desc, gallery index asc).
+// gallery.hip: ONE streaming pass — gallery rows x queries on the matrix cores, per-workgroup top-k lists [gallery_parts][Q][k] kept in
+// LDS while the rows go by (no G x Q matrix in memory); then launch_topk_merge.  qpacked = [ceil64(Q)][dim], zero rows behind Q.
+int gallery_parts(long G, int Q, int* tiles_per_part);
+void launch_gallery_topk(const float* gal, long G, int dim, const float* qpacked, int Q, int k, long idx_base, float* part_score, int* part_idx,
                          hipStream_t s);
 void launch_label(const float* best_score, const int* best_idx, int n, float thr, int* labels, hipStream_t s);
 void launch_topk_merge(const float* part_score, const int* part_idx, int nparts, int Q, int k, float* out_score,
                        int* out_idx, hipStream_t s);
-int gallery_blocks(long G);
 
 // detect -> embed hand-off: first min(count,F) faces per frame, densely packed (n <= 4096 frames)
 void launch_select_faces(const FaceRec* det, const int* counts, int n, int per_frame, int F, FaceRec* faces, int* frame_of,
