@@ -472,14 +472,14 @@ void Recognizer::resize_embed_dev(const uint8_t* frames, int n, int rows, int co
 
 // ------------------------------------------------------------------------------------------ Gallery
 void Gallery::upload(const float* rows, long n, bool device_src, long index_base) {
-    if (dim_ % 32) throw std::runtime_error("gallery: dim must be a multiple of 32");
+    if (dim_ % 64) throw std::runtime_error("gallery: dim must be a multiple of 64");
     rows_.ensure((size_t)n * dim_ * sizeof(float));
     FH_HIP(hipMemcpy(rows_.p, rows, (size_t)n * dim_ * sizeof(float), device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     n_ = n; base_ = index_base;
 }
 
 long Gallery::enroll(const float* rows, long n, bool device_src) {
-    if (dim_ % 32) throw std::runtime_error("gallery: dim must be a multiple of 32");
+    if (dim_ % 64) throw std::runtime_error("gallery: dim must be a multiple of 64");
     const size_t row_bytes = (size_t)dim_ * sizeof(float);
     const size_t need = (size_t)(n_ + n) * row_bytes;
     if (need > rows_.bytes) {                                    // grow geometrically, keeping the enrolled rows
@@ -504,7 +504,7 @@ void Gallery::label_dev(const float* q, int Q, float thr, int* out_label, float*
 
 void Gallery::topk_dev(const float* q, int Q, int k, float* out_score, int* out_idx, hipStream_t s) {
     if (Q <= 0 || Q > 256 || k <= 0 || k > 16) throw std::runtime_error("gallery: need 0 < Q <= 256 and 0 < k <= 16");
-    if (dim_ % 32) throw std::runtime_error("gallery: dim must be a multiple of 32");
+    if (dim_ % 64) throw std::runtime_error("gallery: dim must be a multiple of 64");
     // queries as the GEMM's N operand: whole 64-row tiles, zero rows behind Q (only that tail is cleared)
     const int qrows = (Q + 63) / 64 * 64;
     qpack_.ensure((size_t)qrows * dim_ * sizeof(float));
@@ -515,7 +515,10 @@ void Gallery::topk_dev(const float* q, int Q, int k, float* out_score, int* out_
     ps_.ensure((size_t)std::max(parts, 1) * Q * k * sizeof(float));
     pi_.ensure((size_t)std::max(parts, 1) * Q * k * sizeof(int));
     // ONE pass over the gallery: dot products stay in the MFMA accumulators, per-workgroup top-k lists come out (gallery.hip)
-    launch_gallery_topk(rows_.as<float>(), n_, dim_, qpack_.as<float>(), Q, k, base_, ps_.as<float>(), pi_.as<int>(), s);
+    seed_s_.ensure((size_t)Q * k * sizeof(float));
+    seed_i_.ensure((size_t)Q * k * sizeof(int));
+    launch_gallery_topk(rows_.as<float>(), n_, dim_, qpack_.as<float>(), Q, k, base_, ps_.as<float>(), pi_.as<int>(), seed_s_.as<float>(),
+                        seed_i_.as<int>(), s);
     launch_topk_merge(ps_.as<float>(), pi_.as<int>(), parts, Q, k, out_score, out_idx, s);
     FH_HIP(hipGetLastError());
 }

@@ -134,7 +134,7 @@ class Gallery {
   private:
     int dim_;
     long n_ = 0, base_ = 0;
-    DevBuf rows_, qpack_, ps_, pi_, best_i_;
+    DevBuf rows_, qpack_, ps_, pi_, best_i_, seed_s_, seed_i_;
 };
 
 }  // namespace fh

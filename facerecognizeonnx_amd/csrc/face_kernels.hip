@@ -467,36 +467,78 @@ void launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool better(float s1, int i1, float s2, int i2) { return s1 > s2 || (s1 == s2 && i1 < i2); }
 
-// one workgroup per query: k rounds of "best entry that comes after the previous pick"
+// one workgroup per query: k rounds of "best entry that comes after the previous pick".
+// CACHED: the nparts * k <= 8192 candidate entries are read ONCE into registers (32 per thread) and every round is a register scan +
+// a wave reduction + one LDS hand-off between the four waves; otherwise each round re-reads the lists from memory (L2).
+template <bool CACHED>
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ ps, const int* __restrict__ pi, int nparts, int Q, int k,
                                                          float* __restrict__ out_s, int* __restrict__ out_i) {
     __shared__ float rs[256];
     __shared__ int ri[256];
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int total = nparts * k;
+    constexpr int E = 32;
+    float es[E]; int ei[E];
+    if (CACHED) {
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const int e = j * 256 + tid;
+            es[j] = -2.0f; ei[j] = -1;
+            if (e < total) {
+                const int part = e / k, pos = e - part * k;
+                const size_t o = ((size_t)part * Q + q) * k + pos;
+                es[j] = ps[o]; ei[j] = pi[o];
+            }
+        }
+    }
     float last_s = 0.f; int last_i = -1; bool have_last = false;
     for (int round = 0; round < k; ++round) {
         float best_s = -2.0f; int best_i = 0x7fffffff;
-        for (int e = tid; e < nparts * k; e += 256) {
-            const int part = e / k, p = e - part * k;
-            const size_t o = ((size_t)part * Q + q) * k + p;
-            const float sc = ps[o]; const int gi = pi[o];
-            if (gi < 0) continue;
-            if (have_last && !better(last_s, last_i, sc, gi)) continue;     // must come strictly after the last pick
-            if (better(sc, gi, best_s, best_i)) { best_s = sc; best_i = gi; }
-        }
-        rs[tid] = best_s; ri[tid] = best_i;
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if (tid < st && better(rs[tid + st], ri[tid + st], rs[tid], ri[tid])) { rs[tid] = rs[tid + st]; ri[tid] = ri[tid + st]; }
+        if (CACHED) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) {
+                const float sc = es[j]; const int gi = ei[j];
+                const bool ok = gi >= 0 && (!have_last || better(last_s, last_i, sc, gi)) && better(sc, gi, best_s, best_i);
+                best_s = ok ? sc : best_s; best_i = ok ? gi : best_i;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {               // wave reduction
+                const float os = __shfl_xor(best_s, o); const int oi = __shfl_xor(best_i, o);
+                const bool t = better(os, oi, best_s, best_i);
+                best_s = t ? os : best_s; best_i = t ? oi : best_i;
+            }
+            if (lane == 0) { rs[wv] = best_s; ri[wv] = best_i; }
+            __syncthreads();
+            best_s = rs[0]; best_i = ri[0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w)
+                if (better(rs[w], ri[w], best_s, best_i)) { best_s = rs[w]; best_i = ri[w]; }
+            __syncthreads();
+            last_s = best_s; last_i = best_i;
+        } else {
+            for (int e = tid; e < total; e += 256) {
+                const int part = e / k, pos = e - part * k;
+                const size_t o = ((size_t)part * Q + q) * k + pos;
+                const float sc = ps[o]; const int gi = pi[o];
+                if (gi < 0) continue;
+                if (have_last && !better(last_s, last_i, sc, gi)) continue;     // must come strictly after the last pick
+                if (better(sc, gi, best_s, best_i)) { best_s = sc; best_i = gi; }
+            }
+            rs[tid] = best_s; ri[tid] = best_i;
+            __syncthreads();
+            for (int st = 128; st > 0; st >>= 1) {
+                if (tid < st && better(rs[tid + st], ri[tid + st], rs[tid], ri[tid])) { rs[tid] = rs[tid + st]; ri[tid] = ri[tid + st]; }
+                __syncthreads();
+            }
+            last_s = rs[0]; last_i = ri[0];
             __syncthreads();
         }
-        last_s = rs[0]; last_i = ri[0]; have_last = true;
+        have_last = true;
         if (tid == 0) {
             const bool found = last_i != 0x7fffffff;
             out_s[(size_t)q * k + round] = found ? last_s : -1.0f;
             out_i[(size_t)q * k + round] = found ? last_i : -1;
         }
-        __syncthreads();
         if (last_i == 0x7fffffff) { last_s = -3.0f; }   // nothing left: later rounds find nothing either
     }
 }
@@ -513,7 +555,8 @@ void launch_label(const float* best_score, const int* best_idx, int n, float thr
 
 void launch_topk_merge(const float* part_score, const int* part_idx, int nparts, int Q, int k, float* out_score, int* out_idx,
                        hipStream_t s) {
-    hipLaunchKernelGGL(topk_merge_kernel, dim3(Q), dim3(256), 0, s, part_score, part_idx, nparts, Q, k, out_score, out_idx);
+    if ((long)nparts * k <= 8192) hipLaunchKernelGGL(topk_merge_kernel<true>, dim3(Q), dim3(256), 0, s, part_score, part_idx, nparts, Q, k, out_score, out_idx);
+    else hipLaunchKernelGGL(topk_merge_kernel<false>, dim3(Q), dim3(256), 0, s, part_score, part_idx, nparts, Q, k, out_score, out_idx);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -2,15 +2,19 @@
 // every enrolled row, mapped score (dot + 1) / 2, top-k per query ranked (score desc, global row index asc).
 //
 // One kernel streams the gallery ONCE: the dot products live only in MFMA accumulators, never in memory.
-//   * GEMM part = the tile anatomy of the other f32 kernels (LDS-DMA global_load_lds_dwordx4, [row][32 k] LDS images with the 16-byte
-//     column XOR-swizzled on the source side, one ds_read_b128 per 4 v_mfma_f32_32x32x2_f32).  Workgroup tile: 128 gallery rows x 64
-//     queries, K = dim in 32-deep chunks; the MFMA's A operand is the GALLERY fragment and B the QUERY fragment, so a lane ends up with
-//     ONE query (column) and 16 gallery rows of it per 32x32 block.
-//   * top-k part: every workgroup owns a contiguous run of row tiles and keeps, per query, a sorted k-list and its k-th entry (the
-//     admission threshold) in LDS.  After a tile's K loop each lane compares its 32 scores with the threshold of its query; the few that
-//     pass are appended to that query's slot queue (LDS atomic counter) and 64 threads — one per query — insert them.  A queue holds 32
-//     entries: if a tile overflows one (only the first tiles of a run can, while the lists are still filling), the tile's scores — still
-//     in registers — are replayed in four 32-row rounds, which cannot overflow.
+//   * The scan is an HBM stream with NO reuse on the gallery side: what limits it is bytes in flight (Little: ~50 KB per CU for 5 TB/s at
+//     ~2.5 us loaded latency).  Each wave fetches ITS OWN 32 gallery rows straight into registers — the fragment layout is the one a
+//     ds_read_b128 would deliver: lane (row fr, half fh2) takes 16 bytes at k = (2s + fh2) * 4 of its row; the s-steps of a 128-byte line
+//     are consecutive instructions — in 64-deep chunks, one chunk (8 loads, 32 VGPRs) ahead of the one being multiplied: 8 waves x 8 KB in
+//     flight per CU, no LDS traffic and no barrier on the gallery side.  Only the 64 queries of the tile (shared by the four waves) go
+//     through LDS: 16 KB per chunk by LDS-DMA from L2, double buffered, 16-byte column XOR-swizzled by (row & 15) on the source side.
+//   * v_mfma_f32_32x32x2_f32 with the GALLERY fragment as A and the QUERY fragment as B: a lane ends up with ONE query (column) and 16
+//     gallery rows of it per 32x32 block.  Workgroup tile: 128 gallery rows x 64 queries.
+//   * top-k: every workgroup owns a contiguous run of row tiles.  Thread q < 64 keeps query q's sorted k-list in REGISTERS (a compare-
+//     exchange pass per insertion, no LDS latency chain) and publishes its k-th entry — the admission threshold — in LDS.  After a tile's
+//     K loop each lane compares its 32 scores with the threshold of its query; the few that pass are appended to that query's slot queue
+//     (LDS atomic counter) and thread q inserts them.  A queue holds 32 entries: if a tile overflows one (only the first tiles of a run
+//     can, while the lists are still filling), the tile's scores — still in registers — are replayed in four 32-row rounds, which cannot.
 //   * per-workgroup lists go to memory as [part][Q][k]; topk_merge_kernel (face_kernels.hip) selects the overall top-k.
 // Bounds: HBM scan (G x dim x 4 bytes once) against 2*Q*G*dim FLOP on the f32 matrix cores — at Q = 64 the two meet.
 #include <hip/hip_runtime.h>
@@ -43,23 +47,24 @@ struct GalArgs {
     int dim, Q, k, tiles_n, row_tiles, tiles_per_part;
     float* ps;              // [parts][Q][k]
     int* pi;
+    const float* seed_s;    // optional [Q][k]: exact top-k of a PREFIX of the gallery — its k-th entry is a valid admission threshold for
+    const int* seed_i;      // the whole scan (k rows at least as good exist), so the per-workgroup lists start almost closed
 };
 
 __device__ __forceinline__ bool gal_better(float s1, int i1, float s2, int i2) { return s1 > s2 || (s1 == s2 && i1 < i2); }
 
 __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
-    constexpr int BM = GAL_BM, BN = GAL_BN, TN = BN / 32, AL = BM / 32, BL = BN / 32;
-    __shared__ v4f lds[2][(BM + BN) * 8];
-    __shared__ float lst_s[BN][GAL_KMAX];
-    __shared__ int lst_i[BN][GAL_KMAX];
+    constexpr int BM = GAL_BM, BN = GAL_BN, TN = BN / 32;
+    __shared__ v4f ldsq[2][BN * 16];                          // query chunk [64 rows][64 k], 16-byte column XOR (row & 15)
+    __shared__ float tau_s[BN];                               // admission threshold per query = the k-th entry of its list
+    __shared__ int tau_i[BN];
     __shared__ float que_s[BN][GAL_QCAP];
     __shared__ int que_i[BN][GAL_QCAP];
     __shared__ int cnt[BN];
     __shared__ int overflow;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 31, fh2 = lane >> 5, fsw = (fr >> 1) & 7;
-    // XCD-contiguous block order: the tiles_n workgroups that stream the same rows sit on one XCD (one L2)
+    const int fr = lane & 31, fh2 = lane >> 5;
     int t;
     {
         const int nb = gridDim.x, qq = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
@@ -67,81 +72,99 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
     }
     const int tile_n = t % p.tiles_n, part = t / p.tiles_n;
     const int n0 = tile_n * BN;
-    const int K = p.dim, chunks = K / 32, k = p.k;
+    const int K = p.dim, chunks = K / 64, k = p.k;
     const int rt0 = part * p.tiles_per_part, rt1 = min(p.row_tiles, rt0 + p.tiles_per_part);
 
-    for (int i = tid; i < BN * GAL_KMAX; i += 256) { (&lst_s[0][0])[i] = -1.0f; (&lst_i[0][0])[i] = INT_MAX; }
-    if (tid < BN) cnt[tid] = 0;
+    float ls[GAL_KMAX];                                       // thread q < 64: sorted list of query q (entries >= k stay sentinels)
+    int li[GAL_KMAX];
+#pragma unroll
+    for (int i = 0; i < GAL_KMAX; ++i) { ls[i] = -1.0f; li[i] = INT_MAX; }
+    if (tid < BN) {
+        float ts = -1.0f; int ti = INT_MAX;                       // (-1, INT_MAX): below every real entry (scores are in [0, 1])
+        if (p.seed_i && n0 + tid < p.Q) {
+            const size_t o = (size_t)(n0 + tid) * k + (k - 1);
+            if (p.seed_i[o] >= 0) { ts = p.seed_s[o]; ti = p.seed_i[o]; }
+        }
+        cnt[tid] = 0; tau_s[tid] = ts; tau_i[tid] = ti;
+    }
     if (tid == 0) overflow = 0;
 
-    const int lrow = tid >> 3;
-    const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);
-    const size_t row32 = (size_t)32 * K;
-    v4f* const dstA = &lds[0][wid * 64];
-    v4f* const dstB = &lds[0][BM * 8 + wid * 64];
-    const float* const b_base = p.q + (size_t)(n0 + lrow) * K + lqs * 4;
+    // query loader: pass i fills rows i*16 + (tid >> 4), slot tid & 15 <- source column (tid & 15) ^ (row & 15)
+    const int qrow = tid >> 4;
+    const float* const q_base = p.q + (size_t)(n0 + qrow) * K + (((tid & 15) ^ (qrow & 15)) * 4);
+    const size_t q16 = (size_t)16 * K;
+    v4f* const dstQ = &ldsq[0][wid * 64];
+    const int fsw = fr & 15;
 
     for (int rt = rt0; rt < rt1; ++rt) {
         const long m0 = (long)rt * BM;
-        const float* a_src[AL];
+        const long myrow = m0 + wid * 32 + fr;
+        const bool live = myrow < p.G;
+        const float* a_ptr = (live ? p.gal + (size_t)myrow * K : p.zeros) + fh2 * 4;       // dead rows read the zero line (and are masked below)
+        const int a_step = live ? 64 : 0;
+        const float* q_src = q_base;
+        auto load_q = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < AL; ++i) {
-            const long r = m0 + lrow + 32 * i;
-            a_src[i] = r < p.G ? p.gal + (size_t)r * K + lqs * 4 : p.zeros;     // rows past the end: zero line (and masked below)
-        }
-        const float* b_src = b_base;
-        const bool tail = m0 + BM > p.G;
-        auto load_chunk = [&](int buf) {
-            v4f* const dA = dstA + buf * ((BM + BN) * 8);
-            v4f* const dB = dstB + buf * ((BM + BN) * 8);
+            for (int i = 0; i < 4; ++i) gal_dma16(q_src + i * q16, dstQ + buf * (BN * 16) + i * 256);
+            q_src += 64;
+        };
+        v4f xa[2][8];
+        auto load_a = [&](v4f (&x)[8]) {
 #pragma unroll
-            for (int i = 0; i < AL; ++i) { gal_dma16(a_src[i], dA + i * 32 * 8); if (!tail || m0 + lrow + 32 * i < p.G) a_src[i] += 32; }
-#pragma unroll
-            for (int i = 0; i < BL; ++i) gal_dma16(b_src + i * row32, dB + i * 32 * 8);
-            b_src += 32;
+            for (int s = 0; s < 8; ++s) x[s] = *reinterpret_cast<const v4f*>(a_ptr + s * 8);
+            a_ptr += a_step;
         };
         v16f acc[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-        __syncthreads();                                   // previous tile's epilogue is done with everything
-        load_chunk(0);
-        __syncthreads();
-        for (int kc = 0; kc < chunks; ++kc) {
-            const int buf = kc & 1;
-            if (kc + 1 < chunks) load_chunk(buf ^ 1);
-            const v4f* X = lds[buf] + (wid * 32 + fr) * 8;         // gallery rows of this wave (MFMA A operand)
-            const v4f* Wt = lds[buf] + BM * 8 + fr * 8;            // queries (MFMA B operand)
+        auto multiply = [&](const v4f (&x)[8], int buf) {
+            const v4f* Wt = ldsq[buf] + fr * 16;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < 8; ++s) {
                 const int col = (2 * s + fh2) ^ fsw;
-                const v4f xv = X[col];
                 v4f w[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) w[j] = Wt[j * 32 * 8 + col];
+                for (int j = 0; j < TN; ++j) w[j] = Wt[j * 32 * 16 + col];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[e], w[j][e], acc[j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s][e], w[j][e], acc[j], 0, 0, 0);
             }
+        };
+        __syncthreads();                                   // previous tile's epilogue is done with the LDS lists / queues
+        load_a(xa[0]);
+        load_q(0);
+        int kc = 0;
+        for (; kc + 2 <= chunks; kc += 2) {
+            __syncthreads();                               // queries of chunk kc landed (vmcnt(0) also covers xa[0]); buffer 1 is free
+            load_a(xa[1]);
+            load_q(1);
+            multiply(xa[0], 0);
             __syncthreads();
+            if (kc + 2 < chunks) { load_a(xa[0]); load_q(0); }
+            multiply(xa[1], 1);
         }
-        // ---- top-k epilogue.  C/D map: column (= query) = lane & 31, row (= gallery row of the wave's 32) = (e&3) + 8*(e>>2) + 4*(lane>>5)
+        if (kc < chunks) {                                 // odd number of 64-deep chunks
+            __syncthreads();
+            multiply(xa[0], 0);
+        }
+        // ---- top-k epilogue (as gallery_topk_kernel)
         const long rbase = m0 + wid * 32 + 4 * fh2;
         auto push = [&](int g_lo, int g_hi) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int qi = j * 32 + fr;
-                const float ts = lst_s[qi][k - 1];
-                const int ti = lst_i[qi][k - 1];
+                const float ts = tau_s[qi];
+                const int ti = tau_i[qi];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     if ((e >> 2) < g_lo || (e >> 2) >= g_hi) continue;
                     const long row = rbase + 8 * (e >> 2) + (e & 3);
-                    const float sc = (acc[j][e] + 1.0f) / 2.0f;          // the reference's mapping (face_recognizer.cpp:331-333)
+                    const float sc = (acc[j][e] + 1.0f) / 2.0f;
                     const int gi = (int)(p.idx_base + row);
-                    if (row < p.G && gal_better(sc, gi, ts, ti)) {
+                    if (row < p.G && !gal_better(ts, ti, sc, gi)) {          // at least as good as the threshold entry (which may be this very row)
                         const int slot = atomicAdd(&cnt[qi], 1);
                         if (slot < GAL_QCAP) { que_s[qi][slot] = sc; que_i[qi][slot] = gi; }
                         else overflow = 1;
@@ -149,26 +172,37 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
                 }
             }
         };
-        auto insert = [&]() {                                // one thread per query: its queue into its sorted list
+        auto insert = [&]() {                                // thread q: its queue into its register list, then publish the new threshold
             if (tid < BN) {
                 const int n = min(cnt[tid], GAL_QCAP);
                 for (int c = 0; c < n; ++c) {
-                    const float s = que_s[tid][c];
-                    const int gi = que_i[tid][c];
-                    if (!gal_better(s, gi, lst_s[tid][k - 1], lst_i[tid][k - 1])) continue;
-                    int pos = k - 1;
-                    while (pos > 0 && gal_better(s, gi, lst_s[tid][pos - 1], lst_i[tid][pos - 1])) {
-                        lst_s[tid][pos] = lst_s[tid][pos - 1]; lst_i[tid][pos] = lst_i[tid][pos - 1];
-                        --pos;
+                    float s = que_s[tid][c];
+                    int gi = que_i[tid][c];
+#pragma unroll
+                    for (int pos = 0; pos < GAL_KMAX; ++pos) {      // one compare-exchange pass keeps all 16 slots sorted (score desc, index asc)
+                        const bool sw = gal_better(s, gi, ls[pos], li[pos]);
+                        const float os = ls[pos]; const int oi = li[pos];
+                        ls[pos] = sw ? s : os; li[pos] = sw ? gi : oi;
+                        s = sw ? os : s; gi = sw ? oi : gi;
                     }
-                    lst_s[tid][pos] = s; lst_i[tid][pos] = gi;
+                }
+                if (n > 0) {
+                    int km1 = k - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" : "+v"(km1));                // (keeps the 16 position tests on the vector side: no SGPR mask per slot)
+#endif
+                    float ts = ls[0]; int ti = li[0];
+#pragma unroll
+                    for (int pos = 1; pos < GAL_KMAX; ++pos) { ts = pos == km1 ? ls[pos] : ts; ti = pos == km1 ? li[pos] : ti; }
+                    // the local k-th entry bounds the global one as soon as the list holds k real rows; keep the tighter of it and the seed
+                    if (ti != INT_MAX && gal_better(ts, ti, tau_s[tid], tau_i[tid])) { tau_s[tid] = ts; tau_i[tid] = ti; }
                 }
                 cnt[tid] = 0;
             }
         };
         push(0, 4);
         __syncthreads();
-        if (overflow) {                                      // (block-uniform: read after the barrier) replay in 32-row rounds
+        if (overflow) {
             __syncthreads();
             if (tid < BN) cnt[tid] = 0;
             if (tid == 0) overflow = 0;
@@ -183,14 +217,11 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
             insert();
         }
     }
-    __syncthreads();
-    for (int i = tid; i < BN * k; i += 256) {
-        const int qi = i / k, pos = i - qi * k, qg = n0 + qi;
-        if (qg >= p.Q) continue;
-        const int gi = lst_i[qi][pos];
-        const size_t o = ((size_t)part * p.Q + qg) * k + pos;
-        p.ps[o] = gi == INT_MAX ? -1.0f : lst_s[qi][pos];
-        p.pi[o] = gi == INT_MAX ? -1 : gi;
+    if (tid < BN && n0 + tid < p.Q) {
+        const size_t o = ((size_t)part * p.Q + n0 + tid) * k;
+#pragma unroll
+        for (int pos = 0; pos < GAL_KMAX; ++pos)
+            if (pos < k) { p.ps[o + pos] = li[pos] == INT_MAX ? -1.0f : ls[pos]; p.pi[o + pos] = li[pos] == INT_MAX ? -1 : li[pos]; }
     }
 }
 
@@ -198,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
 int gallery_parts(long G, int Q, int* tiles_per_part) {
     const int tiles_n = (Q + GAL_BN - 1) / GAL_BN;
     const long row_tiles = (G + GAL_BM - 1) / GAL_BM;
-    const int slots = conv_num_cus() * 2;                       // 2 resident workgroups per CU
+    const int slots = conv_num_cus() * 2;                       // 2 resident workgroups per CU (3 measured: no faster, and 768 lists per query leave the merge its slow path)
     long parts = slots / tiles_n;
     if (parts < 1) parts = 1;
     if (parts > row_tiles) parts = row_tiles;
@@ -207,18 +238,30 @@ int gallery_parts(long G, int Q, int* tiles_per_part) {
     return (int)(tpp > 0 ? (row_tiles + tpp - 1) / tpp : 0);
 }
 
-// queries: packed [ceil64(Q)][dim] with zero rows behind Q; part_score / part_idx: [gallery_parts][Q][k]
+// queries: packed [ceil64(Q)][dim] with zero rows behind Q; part_score / part_idx: [gallery_parts][Q][k]; seed_score / seed_idx: [Q][k] scratch.
+// Two passes for a large gallery: the exact top-k of the first GAL_SEED_ROWS rows (same kernel + merge) gives every query an admission
+// threshold, then the full scan runs with it — without the seed every workgroup spends its first tiles sorting rows that cannot matter.
 void launch_gallery_topk(const float* gal, long G, int dim, const float* qpacked, int Q, int k, long idx_base, float* part_score, int* part_idx,
-                         hipStream_t s) {
+                         float* seed_score, int* seed_idx, hipStream_t s) {
     if (G <= 0 || Q <= 0) return;
-    if (dim % 32 || k < 1 || k > GAL_KMAX) throw std::runtime_error("gallery: need dim % 32 == 0 and 1 <= k <= 16");
+    if (dim % 64 || k < 1 || k > GAL_KMAX) throw std::runtime_error("gallery: need dim % 64 == 0 and 1 <= k <= 16");
     if (idx_base + G > (long)INT_MAX) throw std::runtime_error("gallery: global row indices must fit in 31 bits");
     GalArgs a{};
-    a.gal = gal; a.q = qpacked; a.zeros = conv_zero_line(); a.G = G; a.idx_base = idx_base; a.dim = dim; a.Q = Q; a.k = k;
+    a.gal = gal; a.q = qpacked; a.zeros = conv_zero_line(); a.idx_base = idx_base; a.dim = dim; a.Q = Q; a.k = k;
     a.tiles_n = (Q + GAL_BN - 1) / GAL_BN;
+    a.ps = part_score; a.pi = part_idx;
+    constexpr long GAL_SEED_ROWS = 4096;
+    if (G >= 16 * GAL_SEED_ROWS && seed_score && seed_idx) {
+        a.G = GAL_SEED_ROWS;
+        a.row_tiles = (int)(GAL_SEED_ROWS / GAL_BM);
+        const int sp = gallery_parts(a.G, Q, &a.tiles_per_part);
+        hipLaunchKernelGGL(gallery_topk_kernel, dim3((unsigned)(sp * a.tiles_n)), dim3(256), 0, s, a);
+        launch_topk_merge(part_score, part_idx, sp, Q, k, seed_score, seed_idx, s);
+        a.seed_s = seed_score; a.seed_i = seed_idx;
+    }
+    a.G = G;
     a.row_tiles = (int)((G + GAL_BM - 1) / GAL_BM);
     const int parts = gallery_parts(G, Q, &a.tiles_per_part);
-    a.ps = part_score; a.pi = part_idx;
     hipLaunchKernelGGL(gallery_topk_kernel, dim3((unsigned)(parts * a.tiles_n)), dim3(256), 0, s, a);
 }
 

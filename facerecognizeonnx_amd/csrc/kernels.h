@@ -179,7 +179,7 @@ void launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_
 // LDS while the rows go by (no G x Q matrix in memory); then launch_topk_merge.  qpacked = [ceil64(Q)][dim], zero rows behind Q.
 int gallery_parts(long G, int Q, int* tiles_per_part);
 void launch_gallery_topk(const float* gal, long G, int dim, const float* qpacked, int Q, int k, long idx_base, float* part_score, int* part_idx,
-                         hipStream_t s);
+                         float* seed_score, int* seed_idx, hipStream_t s);      // seed_*: [Q][k] scratch (threshold pre-pass of large galleries)
 void launch_label(const float* best_score, const int* best_idx, int n, float thr, int* labels, hipStream_t s);
 void launch_topk_merge(const float* part_score, const int* part_idx, int nparts, int Q, int k, float* out_score,
                        int* out_idx, hipStream_t s);
