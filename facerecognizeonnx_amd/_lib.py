@@ -96,6 +96,7 @@ PROTOTYPES = {
     "fh_image_free": (None, [_vp]),
     "fh_det_set_winograd": (_i, [_vp, _i]),
     "fh_rec_set_winograd": (_i, [_vp, _i]),
+    "fh_rec_set_wino_fusion": (_i, [_vp, _i]),
     "fh_det_set_cus": (_i, [_vp, _i]),
     "fh_rec_set_cus": (_i, [_vp, _i]),
     "fh_det_set_fused_stem": (_i, [_vp, _i]),

@@ -478,6 +478,7 @@ int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k) {
 }
 int fh_det_set_winograd(fh_det* d, int on) { if (!d) return arg_error("null handle"); d->det.net().winograd = on != 0; return FH_OK; }
 int fh_rec_set_winograd(fh_rec* r, int on) { if (!r) return arg_error("null handle"); r->rec.net().winograd = on != 0; return FH_OK; }
+int fh_rec_set_wino_fusion(fh_rec* r, int on) { if (!r) return arg_error("null handle"); r->rec.net().fuse_wino = on != 0; return FH_OK; }
 int fh_det_set_cus(fh_det* d, int cus) { if (!d || cus < 0) return arg_error("bad argument"); d->det.net().cus = cus; return FH_OK; }
 int fh_rec_set_cus(fh_rec* r, int cus) { if (!r || cus < 0) return arg_error("bad argument"); r->rec.net().cus = cus; return FH_OK; }
 int fh_det_set_fused_stem(fh_det* d, int on) { if (!d) return arg_error("null handle"); d->det.net().fuse_stem = on != 0; return FH_OK; }

@@ -141,6 +141,26 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
         if (!dev_[i].wino || prod <= 0 || !dev_[prod].has_aff) continue;        // (op 0 = the stem keeps its own path)
         dev_[i].aff_src = prod; dev_[prod].aff_dst = (int)i;
     }
+    // Consecutive Winograd convolutions on one small map: the output transform of the first and the input transform of the second
+    // run as ONE kernel (winograd.hip, wino_fused_kernel) — the activation between them never makes a round trip through memory.
+    for (size_t i = 0; i + 1 < plan_.ops.size(); ++i) {
+        const POp& a = plan_.ops[i];
+        const POp& b = plan_.ops[i + 1];
+        if (!dev_[i].wino || !dev_[i + 1].wino || a.H != b.H || a.W != b.W || a.Cout != b.Cin || !wino_can_fuse(a.H, a.W, a.Cout)) continue;
+        int feed = -1;
+        if (dev_[i + 1].aff_src == (int)i) feed = 1;                       // next conv applies this op's BatchNorm (second output never written)
+        else if (a.out >= 0 && b.in == a.out) feed = 0;
+        else if (a.out2 >= 0 && b.in == a.out2) feed = 1;
+        if (feed < 0) continue;
+        int other_uses = 0;                                                // does anything besides the next conv's transform read the plain output?
+        if (a.out >= 0) {
+            for (const POp& o : plan_.ops)
+                for (int x : {o.in, o.in2, o.res}) if (x == a.out) ++other_uses;
+            for (const auto& o : plan_.outputs) if (o.tensor == a.out) ++other_uses;
+            if (b.in == a.out) --other_uses;                               // that read is what the fused kernel replaces
+        }
+        dev_[i].fuse_next = true; dev_[i].fuse_feed_aff = feed == 1; dev_[i].fuse_keep_out1 = other_uses > 0;
+    }
     {   // can the first conv take the u8 image directly?  (3x3, Cin = 3 stored as 4, plain epilogue)
         const POp& op = plan_.ops[0];
         stem_ok_ = op.kind == OpKind::CONV && op.in == plan_.input && op.ks == 3 && op.Cin == 4 && op.res < 0 && op.outs.empty() &&
@@ -246,6 +266,7 @@ void Net::run(int batch, hipStream_t s, int first_op) {
     if (batch > cap_) throw std::runtime_error("Net::run: batch exceeds reserved capacity");
     const float* P = params_.as<float>();
     KernelTimer& timer = KernelTimer::get();
+    bool v_ready = false;                                 // the Winograd V workspace already holds the NEXT op's input transform
     for (size_t i = (size_t)first_op; i < plan_.ops.size(); ++i) {
         const POp& op = plan_.ops[i];
         const DevOp& d = dev_[i];
@@ -289,12 +310,27 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                     // 36 GEMMs of depth Cin: short K loops, so the 128x32 tile (4 workgroups per CU) beats the 128x128 one
                     // (IResNet-50, B = 128: 12.75 ms against 14.72 ms)
                     const int wcfg = force_cfg >= 0 ? force_cfg : 2;
-                    const float* in_s = nullptr; const float* in_t = nullptr;
-                    if (d.aff_src >= 0) {
-                        a.in = tensor_ptr(plan_.ops[d.aff_src].out);
-                        in_s = P + dev_[d.aff_src].s2; in_t = P + dev_[d.aff_src].t2;
+                    if (!v_ready) {                                     // (else the previous layer's fused transform already wrote V)
+                        const float* in_s = nullptr; const float* in_t = nullptr;
+                        if (d.aff_src >= 0) {
+                            a.in = tensor_ptr(plan_.ops[d.aff_src].out);
+                            in_s = P + dev_[d.aff_src].s2; in_t = P + dev_[d.aff_src].t2;
+                        }
+                        launch_wino_input(a, wino_v_.as<float>(), in_s, in_t, s);
                     }
-                    launch_conv_winograd(a, P + d.w36, wino_v_.as<float>(), wino_m_.as<float>(), wcfg, in_s, in_t, s);
+                    launch_wino_gemm(a, P + d.w36, wino_v_.as<float>(), wino_m_.as<float>(), wcfg, s);
+                    v_ready = false;
+                    if (d.fuse_next && fuse_wino && i + 1 < plan_.ops.size()) {
+                        const POp& nx = plan_.ops[i + 1];
+                        const bool next_wino = dev_[i + 1].wino && (long)batch * ((nx.H + 3) / 4) * ((nx.W + 3) / 4) >= kWinoMinTiles;
+                        if (next_wino) {
+                            ConvArgs e = a;
+                            if (!d.fuse_keep_out1) e.out1 = nullptr;
+                            launch_wino_fused(e, wino_m_.as<float>(), wino_v_.as<float>(), d.fuse_feed_aff ? 1 : 0, s);
+                            v_ready = true;
+                        }
+                    }
+                    if (!v_ready) launch_wino_output(a, wino_m_.as<float>(), s);
                     tag = 7;
                     break;
                 }

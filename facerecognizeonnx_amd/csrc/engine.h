@@ -44,6 +44,7 @@ class Net {
     int in_w() const { return plan_.inW; }
     int capacity() const { return cap_; }
     bool winograd = true;                                 // Winograd F(4x4,3x3) for the deep 3x3 convs (false: direct form everywhere)
+    bool fuse_wino = true;                                // tuning / test hook: fused output+input transform between consecutive Winograd layers
     int cus = 0;                                          // CUs of the stream this net runs on when it is CU-masked (0 = all)
     int force_cfg = -1;                                   // tuning hook: conv tile config override
     bool sk_enable = true;                                // tuning hook: stream-K remainder wave
@@ -60,6 +61,9 @@ class Net {
         int aff_src = -1;                                     // Winograd op whose input is op[aff_src]'s second (BatchNorm) output and its only
                                                               // consumer: the transform reads op[aff_src].out and applies that affine itself
         int aff_dst = -1;                                     // ... and the producer's side of the same link
+        bool fuse_next = false;                               // Winograd op followed by another on the same small map: fused transform kernel
+        bool fuse_feed_aff = false;                           //   the next conv sees out * s2 + t2 (its block's BatchNorm) instead of out
+        bool fuse_keep_out1 = true;                           //   something else reads the plain output too (e.g. a later residual): write it
         int Kpad = 0;
     };
     float* tensor_ptr(int t) const { return arena_.as<float>() + plan_.tensors[t].offset * (size_t)cap_; }

@@ -151,6 +151,110 @@ __global__ __launch_bounds__(256, 2) void wino_output_kernel(const WinoOutArgs p
     }
 }
 
+// ---- output transform of conv L fused with the input transform of conv L+1 (same map, C = Cout(L) = Cin(L+1)) ---------------------
+// Between two Winograd layers the activation only has to exist long enough to be re-tiled: 4x4 output tiles in, overlapping 6x6 input
+// patches out.  One workgroup takes IMG whole images x 64 channels (14x14: one image, 7x7: four): phase 1 = wino_output_kernel's work
+// (Y = A^T M A, bias -> PReLU / ReLU -> + residual; out1 / out2 written only if something else reads them), the values the next
+// convolution sees — plain, or through its block's pre-conv BatchNorm (feed_aff) — go to an LDS image [pixel][64 channels]; phase 2 =
+// wino_input_kernel's work from that image (zero padding = pixels outside the map).  The activation makes no round trip through memory
+// and one launch disappears per layer (IResNet-50: 29 of the 38 Winograd layers feed another one on a <= 16x16 map).
+struct WinoFuseArgs {
+    WinoOutArgs o;
+    float* V;               // [36][NTp][C] of the next convolution
+    int feed_aff;           // 1: the next convolution reads y * s2 + t2 (its block's BatchNorm), 0: y itself
+};
+
+__global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFuseArgs a) {
+    const WinoOutArgs& p = a.o;
+    extern __shared__ v4f act[];                               // [IMG][H*W][16 float4]
+    const int C = p.C, TPI = p.TY * p.TX, IMG = 16 / TPI, HW = p.H * p.W;
+    const int tid = threadIdx.x, c4l = tid & 15, slot = tid >> 4;
+    const int cslices = C >> 6;
+    const int cs = blockIdx.x % cslices, b0 = (blockIdx.x / cslices) * IMG;
+    const int il = slot / TPI, tile = slot - il * TPI;
+    const int ty = tile / p.TX, tx = tile - ty * p.TX;
+    const int b = b0 + il;
+    const bool live = b < p.B;
+    const int c4 = cs * 16 + c4l;                              // float4 index inside C
+    const size_t fs = (size_t)p.NTp * C;
+    const size_t tg = ((size_t)b * p.TY + ty) * p.TX + tx;    // tile row of the V / M planes
+    if (live) {
+        // ---- phase 1: Y = A^T M A, epilogue, LDS image
+        const float* src = p.M + tg * C + c4 * 4;
+        v4f t[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            v4f m[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const v4f*>(src + (size_t)(i * 6 + j) * fs);
+            v4f y[4];
+            wino_at(m, y);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r][j] = y[r];
+        }
+        const v4f b4 = p.bias ? *reinterpret_cast<const v4f*>(p.bias + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+        v4f sl = {0.f, 0.f, 0.f, 0.f}, s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+        if (p.act == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(p.slope + c4 * 4);
+        if (p.s2) { s2 = *reinterpret_cast<const v4f*>(p.s2 + c4 * 4); t2 = *reinterpret_cast<const v4f*>(p.t2 + c4 * 4); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oy = 4 * ty + r;
+            if (oy >= p.H) continue;
+            v4f y[4];
+            wino_at(t[r], y);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int ox = 4 * tx + x;
+                if (ox >= p.W) continue;
+                v4f v = y[x] + b4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float u = v[e];
+                    if (p.act == (int)Act::RELU) u = u > 0.f ? u : 0.f;
+                    else if (p.act == (int)Act::PRELU) u = u >= 0.f ? u : u * sl[e];
+                    else if (p.act == (int)Act::SIGMOID) u = 1.0f / (1.0f + expf(-u));
+                    v[e] = u;
+                }
+                const size_t o = (((size_t)b * p.H + oy) * p.W + ox) * C + c4 * 4;
+                if (p.res) v += *reinterpret_cast<const v4f*>(p.res + o);
+                if (p.out1) *reinterpret_cast<v4f*>(p.out1 + o) = v;
+                const v4f vb = v * s2 + t2;
+                if (p.out2) *reinterpret_cast<v4f*>(p.out2 + o) = vb;
+                act[(il * HW + oy * p.W + ox) * 16 + c4l] = a.feed_aff ? vb : v;
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    // ---- phase 2: V = B^T d B from the LDS image (6x6 patch, rows / columns 4t-1 .. 4t+4, zeros outside the map)
+    const v4f* img = act + (size_t)il * HW * 16 + c4l;
+    const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
+    v4f tt[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int ix = ix0 + c;
+        v4f d[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int iy = iy0 + r;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            d[r] = ok ? img[(iy * p.W + ix) * 16] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        v4f tc[6];
+        wino_bt(d, tc);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tt[i][c] = tc[i];
+    }
+    float* dst = a.V + tg * C + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v4f o6[6];
+        wino_bt(tt[i], o6);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(dst + (size_t)(i * 6 + j) * fs) = o6[j];
+    }
+}
+
 // ---- the 36 GEMMs: M[f] = V[f] (rows x K) * U[f] (K x N), frequency planes stacked along the rows --------------------------
 // Same tile anatomy as conv_igemm_kernel (LDS-DMA with source-side swizzle, [row][32 k] LDS images, one ds_read_b128 per 4 MFMAs,
 // weights as the MFMA A operand) but nothing else: rows are contiguous, K and N are multiples of 32, the row count a multiple of
@@ -248,21 +352,31 @@ void wino_filter_transform(const double g[9], double u[36]) {
         for (int j = 0; j < 6; ++j) u[i * 6 + j] = t[i][0] * G[j][0] + t[i][1] * G[j][1] + t[i][2] * G[j][2];
 }
 
-// a: the convolution's arguments (in, bias, slope, res, out1, out2, s2, t2, B, H, W, Cin, Cout, act, slabs, ...);
-// wt36 = 36 packed weight images [conv_wt_rows(Cout)][Cin] (U[f]), V / M = workspaces of 36 * tiles * max(Cin, Cout) floats.
-void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, const float* in_scale, const float* in_shift,
-                          hipStream_t s) {
+static void wino_check(long NT, int cmax) {
+    if (NT * (cmax / 4) >= (1L << 31) || 36 * (NT + 256) >= (1L << 31))
+        throw std::runtime_error("winograd: batch too large for the 32-bit tile index (split the batch)");
+}
+
+// stage 1: in [B,H,W,Cin] -> V (optional per-channel affine on in-image pixels)
+void launch_wino_input(const ConvArgs& a, float* V, const float* in_scale, const float* in_shift, hipStream_t s) {
     const int TY = (a.H + 3) / 4, TX = (a.W + 3) / 4;
     const long NT = (long)a.B * TY * TX;
     if (NT <= 0) return;
-    if (NT * (std::max(a.Cin, a.Cout) / 4) >= (1L << 31) || 36 * (NT + 256) >= (1L << 31))
-        throw std::runtime_error("winograd: batch too large for the 32-bit tile index (split the batch)");
-    const long NTp = wino_rows(NT);                          // rows per frequency plane, padded to whole GEMM tiles
+    wino_check(NT, std::max(a.Cin, a.Cout));
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
-    hipLaunchKernelGGL(wino_input_kernel, dim3(wino_grid(NT * (a.Cin >> 2))), dim3(256), 0, s, a.in, V, a.B, a.H, a.W, a.Cin, TY, TX, NTp, in_scale,
+    hipLaunchKernelGGL(wino_input_kernel, dim3(wino_grid(NT * (a.Cin >> 2))), dim3(256), 0, s, a.in, V, a.B, a.H, a.W, a.Cin, TY, TX, wino_rows(NT), in_scale,
                        in_shift);
     timer.end(s, 8, 0.0, 0.0);
+}
+
+// stage 2: the 36 GEMMs  M[f] = V[f] * U[f]   (wt36 = 36 packed weight images [conv_wt_rows(Cout)][Cin])
+void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, float* M, int cfg, hipStream_t s) {
+    const int TY = (a.H + 3) / 4, TX = (a.W + 3) / 4;
+    const long NT = (long)a.B * TY * TX;
+    if (NT <= 0) return;
+    const long NTp = wino_rows(NT);                          // rows per frequency plane, padded to whole GEMM tiles
+    KernelTimer& timer = KernelTimer::get();
     ConvArgs g{};
     g.in = V; g.wt = wt36; g.out1 = M; g.slabs = a.slabs; g.sk_enable = a.sk_enable; g.cus = a.cus;
     g.B = (int)(36 * NTp); g.H = g.W = g.Ho = g.Wo = 1; g.Cin = a.Cin; g.Cout = a.Cout; g.ks = 1; g.stride = 1; g.pad = 0; g.Kpad = a.Cin;
@@ -287,12 +401,57 @@ void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float*
     } else {
         launch_conv(g, cfg, s);                              // generic grouped instantiation of conv_igemm_kernel
     }
+}
+
+static WinoOutArgs wino_out_args(const ConvArgs& a, const float* M) {
+    const int TY = (a.H + 3) / 4, TX = (a.W + 3) / 4;
     WinoOutArgs o{};
     o.M = M; o.bias = a.bias; o.slope = a.slope; o.res = a.res; o.out1 = a.out1; o.out2 = a.out2; o.s2 = a.s2; o.t2 = a.t2;
-    o.B = a.B; o.H = a.H; o.W = a.W; o.C = a.Cout; o.TY = TY; o.TX = TX; o.act = a.act; o.NTp = NTp;
+    o.B = a.B; o.H = a.H; o.W = a.W; o.C = a.Cout; o.TY = TY; o.TX = TX; o.act = a.act; o.NTp = wino_rows((long)a.B * TY * TX);
+    return o;
+}
+
+// stage 3: M -> out (bias -> activation -> + residual -> out1, optional out2 = out1 * s2 + t2)
+void launch_wino_output(const ConvArgs& a, const float* M, hipStream_t s) {
+    const WinoOutArgs o = wino_out_args(a, M);
+    const long NT = (long)a.B * o.TY * o.TX;
+    if (NT <= 0) return;
+    KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
     hipLaunchKernelGGL(wino_output_kernel, dim3(wino_grid(NT * (a.Cout >> 2))), dim3(256), 0, s, o);
     timer.end(s, 8, 0.0, 0.0);
+}
+
+// can stage 3 of this convolution be fused with stage 1 of a following Winograd convolution on the same map?
+bool wino_can_fuse(int H, int W, int C) {
+    const int tpi = ((H + 3) / 4) * ((W + 3) / 4);
+    return C % 64 == 0 && tpi <= 16 && (tpi & (tpi - 1)) == 0;
+}
+
+// stage 3 of convolution `a` + stage 1 of the next one in one kernel: M -> (out1 / out2 if non-null) and -> V of the next convolution,
+// which sees out1 (feed_aff = 0) or out1 * s2 + t2 (feed_aff = 1; a.s2 / a.t2 must then be set even when a.out2 is null).
+void launch_wino_fused(const ConvArgs& a, const float* M, float* Vnext, int feed_aff, hipStream_t s) {
+    if (!wino_can_fuse(a.H, a.W, a.Cout)) throw std::runtime_error("winograd: this map cannot take the fused transform");
+    WinoFuseArgs f{};
+    f.o = wino_out_args(a, M);
+    f.V = Vnext; f.feed_aff = feed_aff;
+    const long NT = (long)a.B * f.o.TY * f.o.TX;
+    if (NT <= 0) return;
+    wino_check(NT, a.Cout);
+    const int img = 16 / (f.o.TY * f.o.TX);
+    const size_t lds = (size_t)img * a.H * a.W * 16 * sizeof(v4f);
+    KernelTimer& timer = KernelTimer::get();
+    timer.begin(s);
+    hipLaunchKernelGGL(wino_fused_kernel, dim3((unsigned)(((a.B + img - 1) / img) * (a.Cout / 64))), dim3(256), lds, s, f);
+    timer.end(s, 8, 0.0, 0.0);
+}
+
+// all three stages of one convolution (used by the single-layer test entry point)
+void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, const float* in_scale, const float* in_shift,
+                          hipStream_t s) {
+    launch_wino_input(a, V, in_scale, in_shift, s);
+    launch_wino_gemm(a, wt36, V, M, cfg, s);
+    launch_wino_output(a, M, s);
 }
 
 }  // namespace fh

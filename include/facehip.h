@@ -186,6 +186,9 @@ FH_API int fh_rec_set_conv_cfg(fh_rec* r, int cfg, int stream_k);
  * fp32 rounding error ~25x the direct form's: see DESIGN.md) unless switched off here; 0 = direct form everywhere. */
 FH_API int fh_det_set_winograd(fh_det* d, int on);
 FH_API int fh_rec_set_winograd(fh_rec* r, int on);
+/* on (default): between two consecutive Winograd layers on a map of <= 16x16 pixels the output transform of the first and the input
+ * transform of the second run as one kernel (the activation stays in LDS); off: separate transform kernels. */
+FH_API int fh_rec_set_wino_fusion(fh_rec* r, int on);
 /* A handle whose stream is restricted to a subset of the CUs (hipExtStreamCreateWithCUMask, e.g. detector and
  * recogniser side by side on disjoint CU sets) should say how many it gets: it sizes the convolution kernels'
  * remainder round.  0 = the whole device (default). */

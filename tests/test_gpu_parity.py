@@ -1144,3 +1144,24 @@ def test_fused_front_equals_separate_kernels():
             outs.append(_det_outputs(det, 2))
         for a, b in zip(*outs):
             np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5, err_msg=f"{rows}x{cols} pitch {pitch}")
+
+
+def test_fused_winograd_transforms_equal_separate_kernels():
+    """Output transform of one Winograd layer + input transform of the next as ONE kernel (the activation stays in LDS) vs the two
+    separate kernels: same arithmetic on the same values, so the raw network outputs must agree to fp32 rounding — on the 14x14 and
+    7x7 stages of the full IResNet-50 (conv1 -> conv2 inside a block, conv2 -> next block's conv1 through its BatchNorm + residual)
+    and with a batch that does not fill the last 4-image group of the 7x7 kernel."""
+    from facerecognizeonnx_amd.synth import models
+    rec = fa.FaceRecognizer()
+    assert rec.loadModel(models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50))
+    for n in (130, 67):                                               # 7x7 needs B >= 64 for Winograd; 130 / 67 are not multiples of 4
+        crops = dev(util.frames_u8(n, 112, 112, seed=300 + n))
+        res = []
+        for on in (1, 0):
+            assert fa.lib().fh_rec_set_wino_fusion(rec.handle, on) == 0
+            raw = torch.zeros((n, 512), device="cuda"); out = torch.zeros((n, 512), device="cuda")
+            assert rec.embed_aligned_dev(crops.data_ptr(), n, out.data_ptr(), raw.data_ptr()) == n
+            torch.cuda.synchronize()
+            res.append(raw.cpu().numpy().astype(np.float64))
+        assert np.isfinite(res[0]).all()
+        assert np.abs(res[0] - res[1]).max() <= 1e-5 * np.abs(res[1]).max(), np.abs(res[0] - res[1]).max()
