@@ -146,7 +146,7 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
     for (size_t i = 0; i + 1 < plan_.ops.size(); ++i) {
         const POp& a = plan_.ops[i];
         const POp& b = plan_.ops[i + 1];
-        if (!dev_[i].wino || !dev_[i + 1].wino || a.H != b.H || a.W != b.W || a.Cout != b.Cin || !wino_can_fuse(a.H, a.W, a.Cout)) continue;
+        if (!dev_[i].wino || !dev_[i + 1].wino || a.H != b.H || a.W != b.W || a.Cout != b.Cin || !wino_can_fuse(a.H, a.W, a.Cout, false)) continue;
         int feed = -1;
         if (dev_[i + 1].aff_src == (int)i) feed = 1;                       // next conv applies this op's BatchNorm (second output never written)
         else if (a.out >= 0 && b.in == a.out) feed = 0;
@@ -159,6 +159,8 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
             for (const auto& o : plan_.outputs) if (o.tensor == a.out) ++other_uses;
             if (b.in == a.out) --other_uses;                               // that read is what the fused kernel replaces
         }
+        const bool writes_out2 = a.out2 >= 0 && dev_[i + 1].aff_src != (int)i;
+        if (!wino_can_fuse(a.H, a.W, a.Cout, other_uses > 0 || a.res >= 0 || writes_out2)) continue;
         dev_[i].fuse_next = true; dev_[i].fuse_feed_aff = feed == 1; dev_[i].fuse_keep_out1 = other_uses > 0;
     }
     {   // can the first conv take the u8 image directly?  (3x3, Cin = 3 stored as 4, plain epilogue)

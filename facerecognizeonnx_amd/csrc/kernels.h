@@ -100,7 +100,7 @@ void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float*
 void launch_wino_input(const ConvArgs& a, float* V, const float* in_scale, const float* in_shift, hipStream_t s);
 void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, float* M, int cfg, hipStream_t s);
 void launch_wino_output(const ConvArgs& a, const float* M, hipStream_t s);
-bool wino_can_fuse(int H, int W, int C);
+bool wino_can_fuse(int H, int W, int C, bool touches_memory);
 void launch_wino_fused(const ConvArgs& a, const float* M, float* Vnext, int feed_aff, hipStream_t s);
 void wino_filter_transform(const double g[9], double u[36]);
 long wino_rows(long tiles);                  // rows per frequency plane of the V / M workspaces (tiles rounded up to 256)     // host: G g G^T of one 3x3 filter

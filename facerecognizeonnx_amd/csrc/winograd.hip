@@ -162,20 +162,24 @@ struct WinoFuseArgs {
     WinoOutArgs o;
     float* V;               // [36][NTp][C] of the next convolution
     int feed_aff;           // 1: the next convolution reads y * s2 + t2 (its block's BatchNorm), 0: y itself
+    // work split: a workgroup takes `img` whole images x (4 * csl4) channels; thread = (image, tile, float4 column).  Maps of <= 16 tiles
+    // (14x14, 7x7): csl4 = 16 (64 channels, whole 256-byte pixel rows per 16 lanes); up to 64 tiles (28x28 = 49): csl4 = 4 (16 channels)
+    // so that the LDS image of one picture still fits.  pitch = float4 slots per pixel in LDS (5 for csl4 = 4: bank spread).
+    int csl4, pitch, img;
 };
 
 __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFuseArgs a) {
     const WinoOutArgs& p = a.o;
-    extern __shared__ v4f act[];                               // [IMG][H*W][16 float4]
-    const int C = p.C, TPI = p.TY * p.TX, IMG = 16 / TPI, HW = p.H * p.W;
-    const int tid = threadIdx.x, c4l = tid & 15, slot = tid >> 4;
-    const int cslices = C >> 6;
+    extern __shared__ v4f act[];                               // [img][H*W][pitch float4]
+    const int C = p.C, TPI = p.TY * p.TX, IMG = a.img, HW = p.H * p.W, PITCH = a.pitch;
+    const int tid = threadIdx.x, c4l = tid % a.csl4, slot = tid / a.csl4;
+    const int cslices = C / (4 * a.csl4);
     const int cs = blockIdx.x % cslices, b0 = (blockIdx.x / cslices) * IMG;
     const int il = slot / TPI, tile = slot - il * TPI;
     const int ty = tile / p.TX, tx = tile - ty * p.TX;
     const int b = b0 + il;
-    const bool live = b < p.B;
-    const int c4 = cs * 16 + c4l;                              // float4 index inside C
+    const bool live = il < IMG && b < p.B;
+    const int c4 = cs * a.csl4 + c4l;                          // float4 index inside C
     const size_t fs = (size_t)p.NTp * C;
     const size_t tg = ((size_t)b * p.TY + ty) * p.TX + tx;    // tile row of the V / M planes
     if (live) {
@@ -220,14 +224,14 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFuseArgs a
                 if (p.out1) *reinterpret_cast<v4f*>(p.out1 + o) = v;
                 const v4f vb = v * s2 + t2;
                 if (p.out2) *reinterpret_cast<v4f*>(p.out2 + o) = vb;
-                act[(il * HW + oy * p.W + ox) * 16 + c4l] = a.feed_aff ? vb : v;
+                act[(il * HW + oy * p.W + ox) * PITCH + c4l] = a.feed_aff ? vb : v;
             }
         }
     }
     __syncthreads();
     if (!live) return;
     // ---- phase 2: V = B^T d B from the LDS image (6x6 patch, rows / columns 4t-1 .. 4t+4, zeros outside the map)
-    const v4f* img = act + (size_t)il * HW * 16 + c4l;
+    const v4f* img = act + (size_t)il * HW * PITCH + c4l;
     const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
     v4f tt[6][6];
 #pragma unroll
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFuseArgs a
         for (int r = 0; r < 6; ++r) {
             const int iy = iy0 + r;
             const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            d[r] = ok ? img[(iy * p.W + ix) * 16] : v4f{0.f, 0.f, 0.f, 0.f};
+            d[r] = ok ? img[(iy * p.W + ix) * PITCH] : v4f{0.f, 0.f, 0.f, 0.f};
         }
         v4f tc[6];
         wino_bt(d, tc);
@@ -423,26 +427,39 @@ void launch_wino_output(const ConvArgs& a, const float* M, hipStream_t s) {
 }
 
 // can stage 3 of this convolution be fused with stage 1 of a following Winograd convolution on the same map?
-bool wino_can_fuse(int H, int W, int C) {
+static bool wino_fuse_shape(int H, int W, int C, int* csl4, int* pitch, int* img) {
     const int tpi = ((H + 3) / 4) * ((W + 3) / 4);
-    return C % 64 == 0 && tpi <= 16 && (tpi & (tpi - 1)) == 0;
+    int c = 0, pt = 0, im = 0;
+    if (C % 64 == 0 && tpi <= 16 && (tpi & (tpi - 1)) == 0) { c = 16; pt = 16; im = 16 / tpi; }
+    else if (C % 16 == 0 && tpi <= 64) { c = 4; pt = 5; im = 64 / tpi; }
+    else return false;
+    if ((size_t)im * H * W * pt * sizeof(v4f) > 64 * 1024) return false;     // the LDS image of `im` pictures
+    if (csl4) { *csl4 = c; *pitch = pt; *img = im; }
+    return true;
+}
+// touches_memory: the fused kernel would also read a residual or write out1 / out2.  On maps of more than 16 tiles it works on 16-channel
+// slices, i.e. 64-byte pieces of every pixel row: fine for the M / V planes, but it halves the efficiency of those activation accesses
+// (28x28x128, B = 128: 116 us fused against 60 + 46 us separate) — such junctions keep the two separate kernels.
+bool wino_can_fuse(int H, int W, int C, bool touches_memory) {
+    int csl4 = 0, pitch = 0, img = 0;
+    if (!wino_fuse_shape(H, W, C, &csl4, &pitch, &img)) return false;
+    return csl4 == 16 || !touches_memory;
 }
 
 // stage 3 of convolution `a` + stage 1 of the next one in one kernel: M -> (out1 / out2 if non-null) and -> V of the next convolution,
 // which sees out1 (feed_aff = 0) or out1 * s2 + t2 (feed_aff = 1; a.s2 / a.t2 must then be set even when a.out2 is null).
 void launch_wino_fused(const ConvArgs& a, const float* M, float* Vnext, int feed_aff, hipStream_t s) {
-    if (!wino_can_fuse(a.H, a.W, a.Cout)) throw std::runtime_error("winograd: this map cannot take the fused transform");
     WinoFuseArgs f{};
+    if (!wino_fuse_shape(a.H, a.W, a.Cout, &f.csl4, &f.pitch, &f.img)) throw std::runtime_error("winograd: this map cannot take the fused transform");
     f.o = wino_out_args(a, M);
     f.V = Vnext; f.feed_aff = feed_aff;
     const long NT = (long)a.B * f.o.TY * f.o.TX;
     if (NT <= 0) return;
     wino_check(NT, a.Cout);
-    const int img = 16 / (f.o.TY * f.o.TX);
-    const size_t lds = (size_t)img * a.H * a.W * 16 * sizeof(v4f);
+    const size_t lds = (size_t)f.img * a.H * a.W * f.pitch * sizeof(v4f);
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
-    hipLaunchKernelGGL(wino_fused_kernel, dim3((unsigned)(((a.B + img - 1) / img) * (a.Cout / 64))), dim3(256), lds, s, f);
+    hipLaunchKernelGGL(wino_fused_kernel, dim3((unsigned)(((a.B + f.img - 1) / f.img) * (a.Cout / (4 * f.csl4)))), dim3(256), lds, s, f);
     timer.end(s, 8, 0.0, 0.0);
 }
 
