@@ -39,6 +39,9 @@ def short(name):
         return f"conv_igemm_kernel<{a[0]},{a[1]},{a[2]},{a[3]}>" + (" grouped (Winograd GEMM)" if grouped else "")
     if base == "conv_fixup_kernel":
         return "conv_fixup_kernel"
+    if base == "dwpw_kernel":                                 # <BN, WM, WN, depthwise stride, float4 columns, direct, fused stem>
+        a = [x.strip() for x in targs.strip("<>").split(",")]
+        return f"dwpw_kernel<{','.join(a)}>".replace("false", "0").replace("true", "1")
     return base + (targs if len(targs) < 24 else "")
 
 
