@@ -102,6 +102,7 @@ PROTOTYPES = {
     "fh_det_set_fused_stem": (_i, [_vp, _i]),
     "fh_rec_set_fused_stem": (_i, [_vp, _i]),
     "fh_det_set_fused_front": (_i, [_vp, _i]),
+    "fh_det_set_halo_conv": (_i, [_vp, _i]),
     "fh_resize_u8c3_dev": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "fh_conv_forward_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fh_conv_winograd_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

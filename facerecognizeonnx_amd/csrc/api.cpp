@@ -464,7 +464,7 @@ int fh_topk_merge_dev(const float* ps, const int* pi, int nparts, int nq, int k,
 // ---------------------------------------------------------------------------------- timing / tuning
 int fh_timing_enable(int on) { fh::KernelTimer::get().enabled = on != 0; return FH_OK; }
 int fh_timing_collect(double* ms, double* flops, double* bytes, long long* launches, int n) {
-    if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need 9-entry arrays");
+    if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need 10-entry arrays");
     return guarded([&] { fh::KernelTimer::get().collect(ms, flops, bytes, launches); return fh::KernelTimer::kTags; });
 }
 int fh_timing_collect_ops(double* ms, double* flops, int* tag, int cap) {
@@ -479,6 +479,7 @@ int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k) {
 int fh_det_set_winograd(fh_det* d, int on) { if (!d) return arg_error("null handle"); d->det.net().winograd = on != 0; return FH_OK; }
 int fh_rec_set_winograd(fh_rec* r, int on) { if (!r) return arg_error("null handle"); r->rec.net().winograd = on != 0; return FH_OK; }
 int fh_rec_set_wino_fusion(fh_rec* r, int on) { if (!r) return arg_error("null handle"); r->rec.net().fuse_wino = on != 0; return FH_OK; }
+int fh_det_set_halo_conv(fh_det* d, int on) { if (!d) return arg_error("null handle"); d->det.net().halo_conv = on != 0; return FH_OK; }
 int fh_det_set_cus(fh_det* d, int cus) { if (!d || cus < 0) return arg_error("bad argument"); d->det.net().cus = cus; return FH_OK; }
 int fh_rec_set_cus(fh_rec* r, int cus) { if (!r || cus < 0) return arg_error("bad argument"); r->rec.net().cus = cus; return FH_OK; }
 int fh_det_set_fused_stem(fh_det* d, int on) { if (!d) return arg_error("null handle"); d->det.net().fuse_stem = on != 0; return FH_OK; }

@@ -276,13 +276,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
         // (valid tap -> real address, padded tap -> zero line) when the tap changes.
         int ld_tap = 0, ld_ci = 0;
         const float* cur[AL];
-        auto tap_setup = [&]() {
+        int adv[AL];                                        // floats a row's pointer advances per chunk: 32, or 0 while it reads the zero line
+        auto tap_setup = [&]() {                            // (a dead row of the 25 088-deep FC would otherwise walk 100 KB past the 8 KiB of zeros)
             const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
             const int toff = (p.ks == 3 ? (ky * p.W + kx) * p.Cin : 0) + ld_ci;
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
                 const unsigned long long real = (unsigned long long)(a_ptr[i] + toff);
-                cur[i] = (const float*)(((a_mask[i] >> ld_tap) & 1u) ? real : zero_addr);
+                const bool on = ((a_mask[i] >> ld_tap) & 1u) != 0;
+                cur[i] = (const float*)(on ? real : zero_addr);
+                adv[i] = on ? 32 : 0;
             }
         };
         if (FAST) {
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
             v4f* const dB = dstB + buf * ((BM + BN) * 8);
             if (FAST) {
 #pragma unroll
-                for (int i = 0; i < AL; ++i) { lds_dma16(cur[i], dA + i * RP * 8); cur[i] += 32; }
+                for (int i = 0; i < AL; ++i) { lds_dma16(cur[i], dA + i * RP * 8); cur[i] += adv[i]; }
 #pragma unroll
                 for (int i = 0; i < BL; ++i) lds_dma16(reinterpret_cast<const float*>(w_base + w_off[i]), dB + i * RP * 8);
                 w_base += 128;

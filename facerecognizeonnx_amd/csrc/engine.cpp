@@ -1,6 +1,7 @@
 // engine.cpp — weight upload, arena management and the launch sequences of the face path.
 #include "engine.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
@@ -65,6 +66,12 @@ int KernelTimer::collect_ops(double* ms, double* flops, int* tag, int cap) {
     return n;
 }
 
+static bool debug_sync() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FACEHIP_DEBUG_SYNC"); v = e ? atoi(e) : 0; }
+    return v != 0;
+}
+
 // ------------------------------------------------------------------------------------------ Net
 
 // Winograd pays from 128 input channels on (IResNet-50, B = 128: 14.13 ms direct, 11.2 ms with >= 256, 10.5 ms with >= 128,
@@ -105,6 +112,20 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
             std::vector<float> packed((size_t)rows * d.Kpad, 0.f);
             conv_pack_weights(op.weight.data(), op.Cout, op.Cin, op.ks, packed.data());
             d.wt = push(packed.data(), packed.size());
+            // thin 3x3 stride-1 convolutions on large maps (SCRFD's FPN / head convs): weights in MFMA fragment order for conv_halo.hip
+            if (op.kind == OpKind::CONV) {
+                ConvArgs probe{};
+                probe.ks = op.ks; probe.stride = op.stride; probe.pad = op.pad; probe.Cin = op.Cin; probe.Cout = op.Cout; probe.act = (int)op.act;
+                probe.res_mode = (int)op.res_mode; probe.H = op.H; probe.W = op.W;
+                float dummy = 0.f;
+                probe.out2 = op.out2 >= 0 ? &dummy : nullptr;
+                if (conv_halo_ok(probe) && op.Ho * op.Wo >= 400) {
+                    std::vector<float> wf(conv_halo_wfrag_floats(op.Cin, op.Cout));
+                    conv_halo_pack_weights(op.weight.data(), op.Cout, op.Cin, wf.data());
+                    d.wfrag = push(wf.data(), wf.size());
+                    d.halo = true;
+                }
+            }
             // Winograd F(4x4,3x3) image of the same filter: U[f] = G g G^T in fp64, one packed [rows][Cin] matrix per frequency
             if (op.kind == OpKind::CONV && op.ks == 3 && op.stride == 1 && op.pad == 1 && op.Cin >= kWinoMinCin && op.Cin % 32 == 0 &&
                 op.Cout % 4 == 0 && op.outs.empty() && op.res_mode != ResMode::UP2X) {
@@ -307,6 +328,11 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 a.t_flops = 2.0 * op.macs * batch; a.t_bytes = op.bytes * batch;
                 // (small batches: the 36 GEMMs would be mostly tile padding and the direct form with split-K is faster —
                 //  measured cross-over at 256 tiles per GEMM: B = 1: 0.98 ms direct / 1.83 ms Winograd, B = 32: 4.82 / 3.88)
+                if (d.halo && halo_conv && force_cfg < 0) {
+                    launch_conv_halo(a, P + d.wfrag, s);
+                    tag = 9;
+                    break;
+                }
                 const bool use_wino = d.wino && winograd && (long)batch * ((op.H + 3) / 4) * ((op.W + 3) / 4) >= kWinoMinTiles;
                 if (use_wino) {
                     // 36 GEMMs of depth Cin: short K loops, so the 128x32 tile (4 workgroups per CU) beats the 128x128 one
@@ -381,6 +407,12 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 break;
         }
         if (!dense) timer.end(s, tag, 2.0 * op.macs * batch, op.bytes * batch);
+        if (debug_sync()) {                                   // FACEHIP_DEBUG_SYNC=1: localise a failing launch to its op
+            fprintf(stderr, "[facehip] op %zu %s batch %d done-launch\n", i, op.name.c_str(), batch); fflush(stderr);
+            const hipError_t e1 = hipGetLastError(), e2 = hipStreamSynchronize(s);
+            if (e1 != hipSuccess || e2 != hipSuccess)
+                throw std::runtime_error("HIP error after op " + std::to_string(i) + " (" + op.name + "): " + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        }
     }
     FH_HIP(hipGetLastError());
 }

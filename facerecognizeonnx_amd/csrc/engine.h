@@ -44,6 +44,7 @@ class Net {
     int in_w() const { return plan_.inW; }
     int capacity() const { return cap_; }
     bool winograd = true;                                 // Winograd F(4x4,3x3) for the deep 3x3 convs (false: direct form everywhere)
+    bool halo_conv = true;                                // tuning / test hook: spatial-tile kernel for the thin 3x3 convolutions
     bool fuse_wino = true;                                // tuning / test hook: fused output+input transform between consecutive Winograd layers
     int cus = 0;                                          // CUs of the stream this net runs on when it is CU-masked (0 = all)
     int force_cfg = -1;                                   // tuning hook: conv tile config override
@@ -57,6 +58,8 @@ class Net {
         size_t wf = 0, bf = 0;                                // ... and with the u8 normalisation folded in (byte order, w / 128; adjusted bias)
         size_t dww = 0, dwb = 0;                              // fused depthwise front end (DWPW)
         size_t w36 = 0;                                       // Winograd F(4,3) weights U[36][rows][Cin]
+        size_t wfrag = 0;                                     // halo-conv weights in MFMA fragment order (conv_halo.hip)
+        bool halo = false;                                    // eligible for the spatial-tile 3x3 kernel
         bool wino = false;                                    // eligible: 3x3 stride 1 pad 1, Cin >= 128
         int aff_src = -1;                                     // Winograd op whose input is op[aff_src]'s second (BatchNorm) output and its only
                                                               // consumer: the transform reads op[aff_src].out and applies that affine itself

@@ -14,7 +14,7 @@ void hip_check(hipError_t e, const char* what);
 // Optional per-launch HIP-event timing of the network kernels (bench.py's roofline leg).
 // Tags: 0..3 = conv_igemm tile configs, 4 = depthwise conv, 5 = other graph ops, 6 = conv stream-K fix-up.
 struct KernelTimer {
-    static constexpr int kTags = 9;      // 0-3 conv tile configs, 4 dw / dwpw, 5 other, 6 fix-up, 7 Winograd GEMM, 8 Winograd transforms
+    static constexpr int kTags = 10;     // 0-3 conv tile configs, 4 dw / dwpw, 5 other, 6 fix-up, 7 Winograd GEMM, 8 Winograd transforms, 9 halo conv
     bool enabled = false;
     void begin(hipStream_t s);
     void end(hipStream_t s, int tag, double flops, double bytes);
@@ -89,6 +89,12 @@ int conv_pick_cfg(long M, int Cout);
 void conv_workspace_init(float* ws);          // zero the counter words of a freshly allocated stream-K workspace
 const float* conv_zero_line();                // 8 KiB of device zeros (target of padded / dead loads)
 int conv_num_cus();                           // compute units of the current device
+// dense 3x3 stride-1 convolutions with 16 input channels and <= 64 output channels on an 8x16 spatial tile with an LDS halo
+// (conv_halo.hip); wfrag = conv_halo_pack_weights' image of the filter
+bool conv_halo_ok(const ConvArgs& a);
+size_t conv_halo_wfrag_floats(int Cin, int Cout);
+void conv_halo_pack_weights(const float* w_ohwi, int Cout, int Cin, float* dst);
+void launch_conv_halo(const ConvArgs& a, const float* wfrag, hipStream_t s);
 // depthwise 3x3 stride 1 (+bias +act) fused with the 1x1 conv that consumes it (dwpw_mfma.hip)
 void launch_dwpw(const ConvArgs& a, hipStream_t s);
 // Winograd F(4x4,3x3) form of a 3x3 stride-1 pad-1 convolution (winograd.hip): a = the convolution's arguments,

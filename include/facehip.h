@@ -173,7 +173,7 @@ FH_API int fh_gallery_label_dev(fh_gallery* g, const float* d_queries, int nq, f
 /* ---- measurement hooks (bench.py): per-launch HIP-event timing of the network kernels.
  * Tags 0..3 = conv_igemm tile configs (128x128, 256x64, 128x32, 64x64), 4 = depthwise / depthwise+pointwise,
  * 5 = other graph ops, 6 = conv stream-K fix-up, 7 = Winograd GEMM (its FLOPs = executed; bytes slot = the layer's
- * direct-form FLOPs), 8 = Winograd transforms.  fh_timing_collect synchronises, fills 9-entry arrays (elapsed ms,
+ * direct-form FLOPs), 8 = Winograd transforms, 9 = spatial-tile (LDS halo) 3x3 convolutions.  fh_timing_collect synchronises, fills 10-entry arrays (elapsed ms,
  * algorithmic FLOP, algorithmic activation bytes, launches) and resets the counters.
  * fh_*_set_conv_cfg forces one tile config for every dense conv of a handle (-1 = automatic)
  * and switches the stream-K remainder wave on/off (tuning / A-B measurements). */
@@ -201,6 +201,9 @@ FH_API int fh_rec_set_fused_stem(fh_rec* r, int on);
 /* on (default): when the graph opens with conv 3x3 (16 channels) -> depthwise 3x3 -> pointwise 1x1 (SCRFD's first block), the stem
  * is computed inside the depthwise -> pointwise kernel and its output map never reaches memory; off: separate kernels. */
 FH_API int fh_det_set_fused_front(fh_det* d, int on);
+/* on (default): dense 3x3 stride-1 convolutions with 16 input and <= 64 output channels on large maps (SCRFD's FPN and head
+ * convolutions) run on 8x16 spatial tiles with an LDS halo (conv_halo.hip); off: the generic implicit-GEMM kernel. */
+FH_API int fh_det_set_halo_conv(fh_det* d, int on);
 
 /* ---- image files -> BGR u8, replaces cv::imread(path) (reference src/main.cpp:42,71-72,140-141; OpenCV's default
  * IMREAD_COLOR: 8-bit BGR, alpha dropped, grey replicated, JPEG EXIF orientation applied).  Host code.  JPEG

@@ -1165,3 +1165,56 @@ def test_fused_winograd_transforms_equal_separate_kernels():
             res.append(raw.cpu().numpy().astype(np.float64))
         assert np.isfinite(res[0]).all()
         assert np.abs(res[0] - res[1]).max() <= 1e-5 * np.abs(res[1]).max(), np.abs(res[0] - res[1]).max()
+
+
+HALO_CASES = [
+    # H,  W,  Cin, Cout, residual   (ragged tiles: H % 8, W % 16 != 0; Cout off the 4 / 32 grid; both n-tile counts)
+    (80, 80, 16, 16, False),
+    (40, 40, 16, 16, True),
+    (21, 37, 16, 16, True),
+    (80, 80, 16, 30, False),
+    (23, 50, 16, 30, False),
+    (40, 24, 16, 64, True),
+    (33, 17, 16, 40, False),
+]
+
+
+@pytest.mark.parametrize("H,W,Cin,Cout,res", HALO_CASES)
+def test_halo_conv_matches_oracle(tmp_path, H, W, Cin, Cout, res):
+    """Spatial-tile 3x3 convolution (conv_halo.hip) inside a small graph — stem conv -> [3x3 (-> ReLU) (+ residual)] — vs the oracle,
+    and vs the generic implicit-GEMM kernel on the same graph."""
+    from facerecognizeonnx_amd.synth.onnx_writer import OnnxBuilder
+    rng = np.random.default_rng(H * 100 + Cin + Cout)
+    b = OnnxBuilder("halo")
+    x = b.add_input("input", [1, 3, H, W])
+    def conv(x, cout, cin, k, relu):
+        w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+        y = b.node("Conv", [x, b.init(b.uid("w"), w), b.init(b.uid("b"), (rng.standard_normal(cout) / 10).astype(np.float32))],
+                   kernel_shape=[k, k], pads=[k // 2] * 4, strides=[1, 1])
+        return b.node("Relu", [y]) if relu else y
+    y0 = conv(x, Cin, 3, 3, True)
+    if res:                                                  # the residual must have Cout channels: a 1x1 projection of the stem map
+        side = conv(y0, Cout, Cin, 1, False)
+        y = b.node("Add", [conv(y0, Cout, Cin, 3, False), side])
+    else:
+        y = conv(y0, Cout, Cin, 3, True)
+    y = b.node("Transpose", [y], perm=[0, 2, 3, 1])
+    b.node("Reshape", [y, b.init("shape", np.array([-1, Cout], np.int64))], outputs=["out"])
+    b.add_output("out", ["A", Cout])
+    path = b.save(str(tmp_path / "halo.onnx"))
+    det = fa.FaceDetector(); odet = oracle.OracleDetector()
+    assert det.loadModel(path) and odet.loadModel(path)
+    n = 3
+    frames = util.frames_u8(n, H, W, seed=Cout)
+    d = dev(frames)
+    outs = []
+    for on in (1, 0):
+        assert fa.lib().fh_det_set_halo_conv(det.handle, on) == 0
+        assert fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), n, H, W, W * 3, H * W * 3, 0) == n
+        torch.cuda.synchronize()
+        outs.append(_det_outputs(det, n)[0])
+    np.testing.assert_allclose(outs[0], outs[1], rtol=1e-5, atol=2e-5)
+    for i in range(n):
+        inp, _ = oracle.det_preprocess(frames[i], W, H)
+        ref = odet.run_network(inp)[0]
+        np.testing.assert_allclose(outs[0][i], ref.reshape(outs[0][i].shape), rtol=1e-5, atol=3e-5)
