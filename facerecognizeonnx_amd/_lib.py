@@ -43,6 +43,7 @@ PROTOTYPES = {
     "fh_last_error": (C.c_char_p, []),
     "fh_init": (_i, [_i]),
     "fh_plan_describe": (_i, [C.c_char_p, _i, _i, C.c_char_p, _i]),
+    "fh_onnx_dump": (_i, [C.c_char_p, C.c_char_p, _i]),
     "fh_det_create": (_vp, [C.c_char_p]),
     "fh_det_destroy": (None, [_vp]),
     "fh_det_input_size": (_i, [_vp, _ip, _ip]),

@@ -85,6 +85,46 @@ int fh_plan_describe(const char* onnx_path, int default_h, int default_w, char* 
     });
 }
 
+int fh_onnx_dump(const char* onnx_path, char* buf, int cap) {
+    if (!onnx_path || !buf || cap <= 0) return arg_error("fh_onnx_dump: null argument");
+    return guarded([&] {
+        const fh::OnnxModel m = fh::load_onnx(onnx_path);
+        std::string s;
+        char tmp[256];
+        auto dims = [&](const std::vector<int64_t>& d) { std::string o; for (size_t i = 0; i < d.size(); ++i) { o += (i ? "," : ""); o += std::to_string(d[i]); } return o; };
+        for (const auto& v : m.inputs) s += "input " + v.name + " [" + dims(v.shape) + "]\n";
+        for (const auto& v : m.outputs) s += "output " + v.name + " [" + dims(v.shape) + "]\n";
+        for (const auto& kv : m.inits) {                                   // (std::map: sorted by name)
+            const fh::OnnxTensor& t = kv.second;
+            double sum = 0, first = 0, last = 0;
+            size_t n = 0;
+            if (!t.f.empty()) { n = t.f.size(); for (float x : t.f) sum += x; first = t.f.front(); last = t.f.back(); }
+            else if (!t.i.empty()) { n = t.i.size(); for (int64_t x : t.i) sum += (double)x; first = (double)t.i.front(); last = (double)t.i.back(); }
+            snprintf(tmp, sizeof tmp, " n=%zu sum=%.9g first=%.9g last=%.9g\n", n, sum, first, last);
+            s += "init " + kv.first + " dtype=" + std::to_string(t.dtype) + " [" + dims(t.dims) + "]" + tmp;
+        }
+        for (const auto& nd : m.nodes) {
+            s += "node " + nd.op + " in=";
+            for (size_t i = 0; i < nd.inputs.size(); ++i) s += (i ? "," : "") + nd.inputs[i];
+            s += " out=";
+            for (size_t i = 0; i < nd.outputs.size(); ++i) s += (i ? "," : "") + nd.outputs[i];
+            for (const auto& av : nd.attrs) {                               // (sorted by name)
+                const fh::OnnxAttr& a = av.second;
+                s += " " + av.first + "=";
+                if (!a.ints.empty()) s += "ints:" + dims(a.ints);
+                else if (!a.floats.empty()) { s += "floats:"; for (size_t i = 0; i < a.floats.size(); ++i) { snprintf(tmp, sizeof tmp, "%s%.9g", i ? "," : "", a.floats[i]); s += tmp; } }
+                else if (!a.s.empty()) s += "s:" + a.s;
+                else if (!a.t.dims.empty() || !a.t.f.empty() || !a.t.i.empty()) s += "t:[" + dims(a.t.dims) + "]";
+                else if (a.f != 0.f) { snprintf(tmp, sizeof tmp, "f:%.9g", a.f); s += tmp; }
+                else s += "i:" + std::to_string(a.i);
+            }
+            s += "\n";
+        }
+        snprintf(buf, (size_t)cap, "%s", s.c_str());
+        return (int)std::min<size_t>(s.size(), (size_t)cap - 1);
+    });
+}
+
 // ---------------------------------------------------------------------------------- detector
 fh_det* fh_det_create(const char* onnx_path) {
     if (!onnx_path) { g_err = "fh_det_create: null path"; return nullptr; }

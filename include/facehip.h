@@ -45,6 +45,11 @@ FH_API int fh_init(int device);
 
 /* ---- host-only introspection (no GPU needed): parse + plan an .onnx, write a text summary. */
 FH_API int fh_plan_describe(const char* onnx_path, int default_h, int default_w, char* buf, int cap);
+/* The reader's own view of an .onnx file (what loadModel hands to the planner, src/face_detector.cpp:20-90 path), one canonical
+ * text line per graph input / output / initializer (name, dtype, dims, element count, fp64 sum, first and last value) / node
+ * (op, inputs, outputs, attributes sorted by name).  Exists so that the wire-format reader can be checked against an independent
+ * protobuf decoder (tests/test_onnx_pin.py).  Returns the text length (truncated to cap - 1) or < 0. */
+FH_API int fh_onnx_dump(const char* onnx_path, char* buf, int cap);
 
 /* ---- FaceDetector ------------------------------------------------------------------------
  * fh_det_create   <- FaceDetector::FaceDetector + loadModel   (src/face_detector.cpp:5-12,20-90)

@@ -261,3 +261,21 @@ def test_oracle_classes_follow_reference_error_behaviour(models_dir):
     f = rec.extractFeature(util.frames_u8(1, 90, 70, seed=8, smooth=True)[0], faces[0])
     assert f.shape == (64,) and abs(float(np.linalg.norm(f)) - 1) < 1e-5
     assert rec.extractFeature(None, faces[0]).size == 0
+
+
+def test_similarity_matches_skimage_golden():
+    """Independent pin (tests/golden/make_similarity_golden.py, scikit-image 0.18.3 in /opt/conda): on all-inlier correspondences the
+    oracle's estimate equals Umeyama's least-squares similarity — what estimateAffinePartial2D's final refit computes
+    (face_recognizer.cpp:110-113).  Narrows the risk on the shared arithmetic; OpenCV's RANSAC itself stays unpinned."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "similarity_skimage.npz"))
+    assert np.array_equal(g["template"], oracle.TEMPLATE.reshape(5, 2))
+    worst = 0.0
+    for pts, want in zip(g["src"], g["expected"]):
+        M = oracle.estimate_similarity(pts)
+        assert M is not None
+        scale = max(1.0, np.abs(want[:, 2]).max())
+        np.testing.assert_allclose(M[:, :2], want[:, :2], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(M[:, 2], want[:, 2], rtol=0, atol=1e-9 * scale * 100)
+        assert abs(M[0, 0] - M[1, 1]) < 1e-15 and abs(M[0, 1] + M[1, 0]) < 1e-15            # a similarity: [[a, -b], [b, a]]
+        worst = max(worst, np.abs(M - want).max())
+    assert worst < 1e-7
