@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, CIN4 == 4 ? 4 : 3) void conv3x3_halo_kernel(co
 // the same shape or none, no second output; maps large enough that 8 x 16 tiles are mostly full)
 bool conv_halo_ok(const ConvArgs& a) {
     return a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 16 && a.Cout <= 64 && a.act != (int)Act::PRELU && !a.out2 &&
-           (a.res_mode == (int)ResMode::NONE || a.res_mode == (int)ResMode::SAME) && a.H >= 16 && a.W >= 16 && a.dw_w == nullptr;
+           (a.res_mode == (int)ResMode::NONE || a.res_mode == (int)ResMode::SAME) && a.H >= 16 && a.W >= 16 && a.dw_w == nullptr && !a.bias_cls;
 }
 
 size_t conv_halo_wfrag_floats(int Cin, int Cout) { return (size_t)9 * (Cin / 8) * ((Cout + 31) / 32) * 64 * 4; }

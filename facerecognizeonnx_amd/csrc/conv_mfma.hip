@@ -121,6 +121,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
         if (m >= M || (only_i >= 0 && i != only_i)) continue;
         const size_t row = (size_t)m * p.Cout;
         size_t rrow = row;
+        const float* __restrict__ bias = p.bias;
+        if (p.bias_cls) {                                   // BatchNorm shift folded in: taps that fall on the zero padding contribute none of it
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int cls = 3 * (oy == 0 ? 0 : oy == p.Ho - 1 ? 2 : 1) + (ox == 0 ? 0 : ox == p.Wo - 1 ? 2 : 1);
+            bias += cls * p.Cout;
+        }
         if (p.res_mode == (int)ResMode::UP2X) {
             const int n = m / HoWo, rem = m - n * HoWo;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -143,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
                 for (int g = 0; g < 4; ++g) {
                     const int co = cb + 8 * g;
                     if (co >= p.Cout) continue;
-                    const v4f b4 = p.bias ? *reinterpret_cast<const v4f*>(p.bias + co) : v4f{0.f, 0.f, 0.f, 0.f};
+                    const v4f b4 = bias ? *reinterpret_cast<const v4f*>(bias + co) : v4f{0.f, 0.f, 0.f, 0.f};
                     v4f sl = {0.f, 0.f, 0.f, 0.f};
                     if (p.act == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(p.slope + co);
                     v4f v;
@@ -161,7 +168,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
                 for (int e = 0; e < 16; ++e) {
                     const int co = cb + 8 * (e >> 2) + (e & 3);
                     if (co >= p.Cout) continue;
-                    float v = apply_act(acc[i][j][e] + (p.bias ? p.bias[co] : 0.f), p.act, p.slope ? p.slope[co] : 0.f);
+                    float v = apply_act(acc[i][j][e] + (bias ? bias[co] : 0.f), p.act, p.slope ? p.slope[co] : 0.f);
                     if (p.res_mode != (int)ResMode::NONE) v += res[rrow + co];
                     if (out1) out1[row + co] = v;
                     if (out2) out2[row + co] = v * p.s2[co] + p.t2[co];

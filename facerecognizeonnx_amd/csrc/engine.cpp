@@ -98,6 +98,42 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
         return off;
     };
     dev_.resize(plan_.ops.size());
+    // IResNet's pre-conv BatchNorm in front of a DIRECT 3x3 convolution (Cin < 128: never Winograd): conv(W, s*x + t) with zero padding
+    // = conv(W*s, x) + sum over the taps that are inside the image of W[tap]*t — the shift term only depends on which border the
+    // output pixel touches, so it becomes one bias vector per border class (9 of them) and the producer's normalised second output
+    // (a full extra activation write: 411 MB behind the stem at B = 128) is never needed.  Exact up to fp32 rounding.
+    for (size_t i = 0; i < plan_.ops.size(); ++i) {
+        POp& c = plan_.ops[i];
+        if (c.bn_src < 0 || c.kind != OpKind::CONV || c.ks != 3 || c.stride != 1 || c.pad != 1 || c.H < 2 || c.W < 2) continue;
+        const bool wino_ok = c.Cin >= kWinoMinCin && c.Cin % 32 == 0 && c.Cout % 4 == 0 && c.outs.empty() && c.res_mode != ResMode::UP2X;
+        const POp& pr = plan_.ops[c.bn_src];
+        if (wino_ok || !c.outs.empty() || (int)pr.s2.size() < c.Cin || pr.out < 0) continue;
+        std::vector<float> b9((size_t)9 * c.Cout);
+        for (int co = 0; co < c.Cout; ++co) {
+            double tap_shift[9];
+            for (int t = 0; t < 9; ++t) {
+                double acc = 0;
+                for (int ci = 0; ci < c.Cin; ++ci) acc += (double)c.weight[((size_t)co * 9 + t) * c.Cin + ci] * pr.t2[ci];
+                tap_shift[t] = acc;
+            }
+            for (int ry = 0; ry < 3; ++ry)
+                for (int rx = 0; rx < 3; ++rx) {
+                    double b = c.bias[co];
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const bool in_y = !(ry == 0 && ky == 0) && !(ry == 2 && ky == 2);
+                            const bool in_x = !(rx == 0 && kx == 0) && !(rx == 2 && kx == 2);
+                            if (in_y && in_x) b += tap_shift[ky * 3 + kx];
+                        }
+                    b9[(size_t)(ry * 3 + rx) * c.Cout + co] = (float)b;
+                }
+            for (int t = 0; t < 9; ++t)
+                for (int ci = 0; ci < c.Cin; ++ci) c.weight[((size_t)co * 9 + t) * c.Cin + ci] *= pr.s2[ci];
+        }
+        c.bias = b9;                                            // [9][Cout]
+        dev_[i].bn_fold_src = c.bn_src;
+        dev_[c.bn_src].bn_fold_dst = true;
+    }
     for (size_t i = 0; i < plan_.ops.size(); ++i) {
         const POp& op = plan_.ops[i];
         DevOp& d = dev_[i];
@@ -275,7 +311,8 @@ void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int st
         timer.begin(s);
         launch_stem_conv_u8(src, img_stride, srcH, srcW, step, batch, plan_.inH, plan_.inW, op.stride, op.Cout, P + d.w27, P + d.bias, P + d.wf,
                             P + d.bf, d.has_slope ? P + d.slope : nullptr, (int)op.act, op.out >= 0 ? tensor_ptr(op.out) : nullptr,
-                            op.out2 >= 0 ? tensor_ptr(op.out2) : nullptr, d.has_aff ? P + d.s2 : nullptr, d.has_aff ? P + d.t2 : nullptr, s);
+                            op.out2 >= 0 && !d.bn_fold_dst ? tensor_ptr(op.out2) : nullptr, d.has_aff ? P + d.s2 : nullptr,
+                            d.has_aff ? P + d.t2 : nullptr, s);
         timer.end(s, 5, 2.0 * op.macs * batch, op.bytes * batch);
         run(batch, s, 1);
         return;
@@ -307,6 +344,8 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 a.res = op.res >= 0 ? tensor_ptr(op.res) : nullptr;
                 a.out1 = op.out >= 0 ? tensor_ptr(op.out) : nullptr;
                 a.out2 = op.out2 >= 0 ? tensor_ptr(op.out2) : nullptr;
+                if (d.bn_fold_dst) a.out2 = nullptr;                       // its only reader has the BatchNorm folded into its weights
+                if (d.bn_fold_src >= 0) { a.in = tensor_ptr(plan_.ops[d.bn_fold_src].out); a.bias_cls = 1; }
                 if (d.aff_dst >= 0 && winograd) {                          // its only reader applies the BatchNorm itself (see aff_src)
                     const POp& c = plan_.ops[d.aff_dst];
                     if ((long)batch * ((c.H + 3) / 4) * ((c.W + 3) / 4) >= kWinoMinTiles) a.out2 = nullptr;

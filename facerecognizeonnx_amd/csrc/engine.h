@@ -64,6 +64,9 @@ class Net {
         int aff_src = -1;                                     // Winograd op whose input is op[aff_src]'s second (BatchNorm) output and its only
                                                               // consumer: the transform reads op[aff_src].out and applies that affine itself
         int aff_dst = -1;                                     // ... and the producer's side of the same link
+        int bn_fold_src = -1;                                 // direct 3x3 conv with its block's BatchNorm folded in (weights * s, 9-class bias):
+                                                              // reads op[bn_fold_src].out, whose second output is then never written
+        bool bn_fold_dst = false;                             // ... and the producer's side: skip out2
         bool fuse_next = false;                               // Winograd op followed by another on the same small map: fused transform kernel
         bool fuse_feed_aff = false;                           //   the next conv sees out * s2 + t2 (its block's BatchNorm) instead of out
         bool fuse_keep_out1 = true;                           //   something else reads the plain output too (e.g. a later residual): write it

@@ -40,7 +40,8 @@ struct KernelTimer {
 struct ConvArgs {
     const float* in;        // [B,H,W,Cin]
     const float* wt;        // packed [CoutPad][Kpad], rows >= Cout and cols >= Ktot are zero
-    const float* bias;      // [Cout]
+    const float* bias;      // [Cout] — or, with bias_cls != 0, [9][Cout]: one vector per border class of the output pixel
+                            // (3 * (oy == 0 ? 0 : oy == Ho-1 ? 2 : 1) + same for ox): a pre-conv BatchNorm folded into this 3x3 pad-1 conv
     const float* slope;     // [Cout] (PReLU) or null
     const float* res;       // residual [B,Ho,Wo,Cout] (SAME) / [B,Ho/2,Wo/2,Cout] (UP2X) or null
     float* out1;            // [B,Ho,Wo,Cout] or null
@@ -52,6 +53,7 @@ struct ConvArgs {
     int B, H, W, Cin, Ho, Wo, Cout;
     int ks, stride, pad;
     int Kpad;               // multiple of 32
+    int bias_cls;           // see bias
     int act;                // fh::Act
     int res_mode;           // fh::ResMode
     const float* dw_w;      // fused depthwise 3x3 front end (launch_dwpw): weights [9][Cin], bias [Cin], activation
