@@ -1218,3 +1218,37 @@ def test_halo_conv_matches_oracle(tmp_path, H, W, Cin, Cout, res):
         inp, _ = oracle.det_preprocess(frames[i], W, H)
         ref = odet.run_network(inp)[0]
         np.testing.assert_allclose(outs[0][i], ref.reshape(outs[0][i].shape), rtol=1e-5, atol=3e-5)
+
+
+@pytest.mark.timeout(300)
+def test_two_streams_full_size_models_remainder_rounds():
+    """Full-size det_500m and IResNet-50 on two HIP streams at once (fh_pipeline_submit_dev, three batches in flight), with batch sizes
+    whose convolutions all end in a stream-K remainder round (owner workgroups wait for helper workgroups of the SAME launch): the
+    helpers have lower block indices and are therefore dispatched first, so an owner can never wait for a helper that has no slot —
+    also when another stream's kernels occupy part of the chip.  Results must equal the serial entry point bit for bit."""
+    from facerecognizeonnx_amd.synth import models
+    det = fa.FaceDetector(); rec = fa.FaceRecognizer()
+    assert det.loadModel(models.cached("det_500m_seed100.onnx", models.make_det_500m))
+    assert rec.loadModel(models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50))
+    n, F, K = 23, 3, 3                                                   # 69 faces: ragged tile counts in every stage
+    batches = [dev(util.frames_u8(n, 640, 640, seed=500 + k)) for k in range(K)]
+    ref = []
+    for k in range(K):
+        f = torch.zeros((n * F, 15), device="cuda"); o = torch.zeros(n * F, dtype=torch.int32, device="cuda"); e = torch.zeros((n * F, 512), device="cuda")
+        t = fa.pipeline_run_dev(det, rec, batches[k].data_ptr(), n, 640, 640, F, f.data_ptr(), o.data_ptr(), e.data_ptr())
+        torch.cuda.synchronize()
+        ref.append((t, f[:t].clone(), o[:t].clone(), e[:t].clone()))
+    sd, sr = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(2):
+        for k in range(K):
+            f = torch.zeros((n * F, 15), device="cuda"); o = torch.zeros(n * F, dtype=torch.int32, device="cuda")
+            e = torch.zeros((n * F, 512), device="cuda"); t = torch.zeros(1, dtype=torch.int32, device="cuda")
+            got = fa.pipeline_submit_dev(det, rec, batches[k].data_ptr(), n, 640, 640, F, f.data_ptr(), o.data_ptr(), e.data_ptr(), t.data_ptr(),
+                                         sd.cuda_stream, sr.cuda_stream)
+            outs.append((k, got, f, o, e))
+    torch.cuda.synchronize()
+    for k, got, f, o, e in outs:
+        rt, rf, ro, re_ = ref[k]
+        assert got == rt == n * F
+        assert torch.equal(f[:rt].view(torch.int32), rf.view(torch.int32)) and torch.equal(o[:rt], ro) and torch.equal(e[:rt], re_)
