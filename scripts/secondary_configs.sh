@@ -7,6 +7,7 @@ run c2_embed --workload embed
 run c3_detect --workload detect
 run f4 --faces-per-frame 4
 run c4_gallery --gallery 1000000 --frames 64
+run c4_match --workload match --gallery 1000000 --queries 64 --topk 16
 run from_host --from-host
 run overlap --overlap
 run mbf_embed --workload embed --recogniser mbf
