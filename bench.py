@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2516.8    # the same table: BF16 MFMA = 16x the f32 matrix rate, dense (~2.5 PF)
 CFG_NAMES = ["conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<256,64,4,1>", "conv_igemm_kernel<128,32,4,1>",
              "conv_igemm_kernel<64,64,2,2>", "dwpw_kernel (incl. the fused stem front) + dwconv3x3 kernels", "other graph ops (incl. stem_conv_u8)",
              "conv_fixup_kernel", "wino_gemm_kernel<64, 3>", "wino_input_kernel + wino_output_kernel + wino_fused_kernel",
@@ -65,6 +66,8 @@ def parse():
                     "uploaded over PCIe, double-buffered on a side stream (the PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--recogniser", default="r50", choices=["r50", "mbf"], help="r50 = w600k_r50 (the reference's model, headline); "
                     "mbf = w600k_mbf (MobileFaceNet, the buffalo_s / buffalo_sc recogniser): a secondary measurement")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16x2"], help="fp32 = the reference's arithmetic (headline). bf16x2 = "
+                    "SECONDARY line: opt-in split-bf16 Winograd GEMMs (fh_rec_set_precision, gated on 1 - cos < 1e-3 against fp32)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) on a real multi-GPU node; gloo only to rehearse the N>1 code path")
     ap.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal only: every rank uses cuda:0")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous rehearsal without a GPU: ranks start, meet on gloo, "
@@ -287,6 +290,7 @@ def main():
     det, rec = fa.FaceDetector(), fa.FaceRecognizer()
     if not det.loadModel(det_path) or not rec.loadModel(rec_path):
         raise SystemExit("model load failed: " + fa._lib.last_error())
+    prec_gate = rec.set_precision(args.precision) if args.precision != "fp32" else None   # raises if the library's own gate refuses
 
     B, F = args.frames, args.faces_per_frame
     rng = np.random.default_rng(rank)
@@ -502,6 +506,17 @@ def main():
                                         "frac": gbs / 8000.0, "traffic": None, "launches": int(ln[4]), "avg_launch_us": 1e3 * ms[4] / ln[4],
                                         "algorithmic_gflop_per_launch": None,
                                         "algorithmic_mbytes_per_launch": by[4] / ln[4] / 1e6})
+        if args.precision != "fp32":
+            out["dtype"] = "f32 with split-bf16 (bf16 hi + bf16 mid per operand, 3 bf16 MFMAs, f32 accumulate) Winograd GEMMs"
+            out["secondary"] = True
+            out["config"]["precision"] = {"mode": args.precision, "gate": "max(1 - cos) vs the fp32 path on the library's fixed 64-crop batch < 1e-3",
+                                          "measured_max_1_minus_cos": prec_gate}
+            r = out.get("roofline")
+            if r and r.get("kernel") == CFG_NAMES[7]:
+                # the GEMM's product is executed as three bf16 MFMAs: price those against the dense bf16 peak
+                r.update({"f32_equivalent_achieved": r["achieved"], "achieved": 3 * r["achieved"], "peak": BF16_MFMA_PEAK_TFLOPS,
+                          "frac": 3 * r["achieved"] / BF16_MFMA_PEAK_TFLOPS,
+                          "flops_counted": "3 bf16 products (hi*hi, hi*mid, mid*hi) per f32-equivalent product of the 36 Winograd GEMMs"})
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(det_path, rec_path, host, args)                  # the reference's own setting: 4 threads
             ncpu = out["cpu_baseline"]["host_cores_available"]

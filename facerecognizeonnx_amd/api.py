@@ -177,6 +177,21 @@ class FaceRecognizer:
     def set_chunk(self, n: int):
         check(_lib.lib().fh_rec_set_chunk(self._h, n), "fh_rec_set_chunk")
 
+    def set_precision(self, mode: str = "fp32") -> float:
+        """"fp32" (default, the reference's arithmetic) or "bf16x2" (split-bf16 Winograd GEMMs, opt-in).  The library gates the
+        switch on its own check (max 1 - cos < 1e-3 against fp32 on a fixed batch) and raises if it fails, staying fp32.
+        Returns the measured max(1 - cos)."""
+        import ctypes as C
+        modes = {"fp32": 0, "bf16x2": 1}
+        if mode not in modes:
+            raise ValueError(f"precision {mode!r}: expected one of {sorted(modes)}")
+        worst = C.c_float(0.0)
+        check(_lib.lib().fh_rec_set_precision(self._h, modes[mode], C.byref(worst)), "fh_rec_set_precision")
+        return float(worst.value)
+
+    def precision(self) -> str:
+        return "bf16x2" if _lib.lib().fh_rec_get_precision(self._h) == 1 else "fp32"
+
     def embed_aligned_dev(self, crops_ptr: int, n: int, out_ptr: int, raw_ptr: int = 0, stream: int = 0) -> int:
         return check(_lib.lib().fh_rec_embed_aligned_dev(self._h, crops_ptr, n, out_ptr, raw_ptr, stream),
                      "fh_rec_embed_aligned_dev")

@@ -519,6 +519,61 @@ int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k) {
 int fh_det_set_winograd(fh_det* d, int on) { if (!d) return arg_error("null handle"); d->det.net().winograd = on != 0; return FH_OK; }
 int fh_rec_set_winograd(fh_rec* r, int on) { if (!r) return arg_error("null handle"); r->rec.net().winograd = on != 0; return FH_OK; }
 int fh_rec_set_wino_fusion(fh_rec* r, int on) { if (!r) return arg_error("null handle"); r->rec.net().fuse_wino = on != 0; return FH_OK; }
+// Opt-in precision mode of the recogniser, gated: the mode is only entered if, on a fixed pseudo-random batch of aligned crops, every
+// embedding it produces stays within 1 - cos < 1e-3 of the fp32 path's (north-star tolerance).  Otherwise the handle stays fp32.
+int fh_rec_set_precision(fh_rec* r, int mode, float* worst_out) {
+    if (!r || (mode != FH_PREC_FP32 && mode != FH_PREC_BF16X2)) return arg_error("fh_rec_set_precision: bad argument");
+    if (worst_out) *worst_out = 0.f;
+    if (mode == FH_PREC_FP32) return guarded([&] { r->rec.net().set_bf16x2(false, nullptr); return (int)FH_OK; });
+    return guarded([&] {
+        fh::Net& net = r->rec.net();
+        const int n = 64, dim = r->rec.dim();
+        const size_t crop = (size_t)net.in_h() * net.in_w() * 3;
+        std::vector<uint8_t> h((size_t)n * crop);
+        uint32_t st = 0x9E3779B9u;
+        for (int i = 0; i < n; ++i) {                                   // smooth ramp + noise, a different mix per crop
+            const int amp = 16 + 3 * i;
+            for (size_t e = 0; e < crop; ++e) {
+                st = st * 1664525u + 1013904223u;
+                const int px = (int)(e / 3) % net.in_w(), py = (int)(e / 3) / net.in_w();
+                const int v = 128 + ((px * (i + 1) + py * (n - i)) % 97 - 48) + (int)((st >> 24) % (2 * amp + 1)) - amp;
+                h[(size_t)i * crop + e] = (uint8_t)std::min(255, std::max(0, v));
+            }
+        }
+        fh::DevBuf dc, de;
+        dc.ensure(h.size()); de.ensure((size_t)2 * n * dim * sizeof(float));
+        FH_HIP(hipMemcpy(dc.p, h.data(), h.size(), hipMemcpyHostToDevice));
+        const bool was = net.bf16x2();
+        net.set_bf16x2(false, nullptr);
+        r->rec.embed_aligned_dev(dc.as<uint8_t>(), n, de.as<float>(), nullptr);
+        const int layers = net.set_bf16x2(true, nullptr);
+        if (layers == 0) { net.set_bf16x2(was, nullptr); throw std::runtime_error("fh_rec_set_precision: this model has no layer with a split-bf16 form"); }
+        r->rec.embed_aligned_dev(dc.as<uint8_t>(), n, de.as<float>() + (size_t)n * dim, nullptr);
+        std::vector<float> e((size_t)2 * n * dim);
+        FH_HIP(hipDeviceSynchronize());
+        FH_HIP(hipMemcpy(e.data(), de.p, e.size() * sizeof(float), hipMemcpyDeviceToHost));
+        double worst = 0;
+        for (int i = 0; i < n; ++i) {
+            double dot = 0, na = 0, nb = 0;
+            for (int c = 0; c < dim; ++c) {
+                const double a = e[(size_t)i * dim + c], b = e[(size_t)(n + i) * dim + c];
+                dot += a * b; na += a * a; nb += b * b;
+            }
+            const double err = (na > 0 && nb > 0) ? 1.0 - dot / std::sqrt(na * nb) : 1.0;
+            worst = std::max(worst, std::isfinite(err) ? err : 1.0);
+        }
+        if (worst_out) *worst_out = (float)worst;
+        double gate = 1e-3;                                             // FACEHIP_PRECISION_GATE may only TIGHTEN it (tests of the refusal path)
+        if (const char* g = getenv("FACEHIP_PRECISION_GATE")) gate = std::min(gate, atof(g));
+        if (!(worst < gate)) {
+            net.set_bf16x2(false, nullptr);
+            throw std::runtime_error("fh_rec_set_precision: split-bf16 embeddings differ from fp32 by 1 - cos = " + std::to_string(worst) +
+                                 " (gate " + std::to_string(gate) + "): staying fp32");
+        }
+        return layers;
+    });
+}
+int fh_rec_get_precision(fh_rec* r) { return r && r->rec.net().bf16x2() ? FH_PREC_BF16X2 : FH_PREC_FP32; }
 int fh_det_set_halo_conv(fh_det* d, int on) { if (!d) return arg_error("null handle"); d->det.net().halo_conv = on != 0; return FH_OK; }
 int fh_det_set_cus(fh_det* d, int cus) { if (!d || cus < 0) return arg_error("bad argument"); d->det.net().cus = cus; return FH_OK; }
 int fh_rec_set_cus(fh_rec* r, int cus) { if (!r || cus < 0) return arg_error("bad argument"); r->rec.net().cus = cus; return FH_OK; }

@@ -178,7 +178,9 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
                     conv_pack_weights(uf.data(), op.Cout, op.Cin, 1, u36.data() + (size_t)f * rows * op.Cin);
                 }
                 d.w36 = push(u36.data(), u36.size());
+                d.w36n = u36.size();
                 d.wino = true;
+                d.bf2 = wino_gemm_ok_bf16x2(op.Cin, op.Cout);
                 const size_t tiles = (size_t)((op.H + 3) / 4) * ((op.W + 3) / 4);
                 wino_elems_ = std::max(wino_elems_, 36 * tiles * (size_t)std::max(op.Cin, op.Cout));
                 wino_maxc_ = std::max(wino_maxc_, (size_t)std::max(op.Cin, op.Cout));
@@ -321,6 +323,20 @@ void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int st
     run(batch, s, 0);
 }
 
+int Net::set_bf16x2(bool on, hipStream_t s) {
+    int layers = 0;
+    size_t total = 0;
+    for (auto& d : dev_) if (d.wino && d.bf2) { d.w36p = total; total += d.w36n; ++layers; }
+    if (on && layers > 0 && w36_bf_.bytes < total * sizeof(float)) {
+        w36_bf_.ensure(total * sizeof(float));
+        for (const auto& d : dev_)
+            if (d.wino && d.bf2) launch_pack_bf16x2(params_.as<float>() + d.w36, w36_bf_.as<float>() + d.w36p, (long)d.w36n, s);
+        FH_HIP(hipStreamSynchronize(s));
+    }
+    bf16x2_ = on && layers > 0;
+    return on ? layers : 0;
+}
+
 void Net::run(int batch, hipStream_t s, int first_op) {
     if (batch <= 0) return;
     if (batch > cap_) throw std::runtime_error("Net::run: batch exceeds reserved capacity");
@@ -377,15 +393,16 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                     // 36 GEMMs of depth Cin: short K loops, so the 128x32 tile (4 workgroups per CU) beats the 128x128 one
                     // (IResNet-50, B = 128: 12.75 ms against 14.72 ms)
                     const int wcfg = force_cfg >= 0 ? force_cfg : 2;
+                    const bool bf2 = bf16x2_ && d.bf2 && force_cfg < 0;
                     if (!v_ready) {                                     // (else the previous layer's fused transform already wrote V)
                         const float* in_s = nullptr; const float* in_t = nullptr;
                         if (d.aff_src >= 0) {
                             a.in = tensor_ptr(plan_.ops[d.aff_src].out);
                             in_s = P + dev_[d.aff_src].s2; in_t = P + dev_[d.aff_src].t2;
                         }
-                        launch_wino_input(a, wino_v_.as<float>(), in_s, in_t, s);
+                        launch_wino_input(a, wino_v_.as<float>(), in_s, in_t, bf2, s);
                     }
-                    launch_wino_gemm(a, P + d.w36, wino_v_.as<float>(), wino_m_.as<float>(), wcfg, s);
+                    launch_wino_gemm(a, bf2 ? w36_bf_.as<float>() + d.w36p : P + d.w36, wino_v_.as<float>(), wino_m_.as<float>(), wcfg, bf2, s);
                     v_ready = false;
                     if (d.fuse_next && fuse_wino && i + 1 < plan_.ops.size()) {
                         const POp& nx = plan_.ops[i + 1];
@@ -393,7 +410,8 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                         if (next_wino) {
                             ConvArgs e = a;
                             if (!d.fuse_keep_out1) e.out1 = nullptr;
-                            launch_wino_fused(e, wino_m_.as<float>(), wino_v_.as<float>(), d.fuse_feed_aff ? 1 : 0, s);
+                            launch_wino_fused(e, wino_m_.as<float>(), wino_v_.as<float>(), d.fuse_feed_aff ? 1 : 0,
+                                              bf16x2_ && dev_[i + 1].bf2 && force_cfg < 0, s);
                             v_ready = true;
                         }
                     }

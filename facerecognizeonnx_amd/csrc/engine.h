@@ -46,6 +46,10 @@ class Net {
     bool winograd = true;                                 // Winograd F(4x4,3x3) for the deep 3x3 convs (false: direct form everywhere)
     bool halo_conv = true;                                // tuning / test hook: spatial-tile kernel for the thin 3x3 convolutions
     bool fuse_wino = true;                                // tuning / test hook: fused output+input transform between consecutive Winograd layers
+    // opt-in precision mode (fh_rec_set_precision): the Winograd GEMMs take split-bf16 operands (hi + mid bf16 per value, three bf16 MFMAs,
+    // f32 accumulate); transforms, epilogues and every other layer stay fp32.  Returns the number of layers that switch.
+    int set_bf16x2(bool on, hipStream_t s);
+    bool bf16x2() const { return bf16x2_; }
     int cus = 0;                                          // CUs of the stream this net runs on when it is CU-masked (0 = all)
     int force_cfg = -1;                                   // tuning hook: conv tile config override
     bool sk_enable = true;                                // tuning hook: stream-K remainder wave
@@ -58,6 +62,8 @@ class Net {
         size_t wf = 0, bf = 0;                                // ... and with the u8 normalisation folded in (byte order, w / 128; adjusted bias)
         size_t dww = 0, dwb = 0;                              // fused depthwise front end (DWPW)
         size_t w36 = 0;                                       // Winograd F(4,3) weights U[36][rows][Cin]
+        size_t w36n = 0, w36p = 0;                            // ... their float count; offset of the split-bf16 copy in w36_bf_ (bf2 layers)
+        bool bf2 = false;                                     // this layer's GEMM has a split-bf16 form
         size_t wfrag = 0;                                     // halo-conv weights in MFMA fragment order (conv_halo.hip)
         bool halo = false;                                    // eligible for the spatial-tile 3x3 kernel
         bool wino = false;                                    // eligible: 3x3 stride 1 pad 1, Cin >= 128
@@ -75,7 +81,8 @@ class Net {
     float* tensor_ptr(int t) const { return arena_.as<float>() + plan_.tensors[t].offset * (size_t)cap_; }
     Plan plan_;
     std::vector<DevOp> dev_;
-    DevBuf params_, arena_, partial_, wino_v_, wino_m_;
+    DevBuf params_, arena_, partial_, wino_v_, wino_m_, w36_bf_;
+    bool bf16x2_ = false;
     size_t wino_maxc_ = 0;
     size_t wino_elems_ = 0;                                   // per image: 36 * tiles * max(Cin, Cout) of the largest Winograd op
     int cap_ = 0;

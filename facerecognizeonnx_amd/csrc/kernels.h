@@ -105,11 +105,14 @@ void launch_dwpw(const ConvArgs& a, hipStream_t s);
 void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, const float* in_scale, const float* in_shift,
                           hipStream_t s);
 // the three stages separately, and stage 3 of one convolution fused with stage 1 of the next (same map, C = Cout = next Cin)
-void launch_wino_input(const ConvArgs& a, float* V, const float* in_scale, const float* in_shift, hipStream_t s);
-void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, float* M, int cfg, hipStream_t s);
+// pack / bf16x2 / pack_next: the opt-in split-bf16 operand format (V and U as (hi, mid) bf16 pairs in 32-bit words, see winograd.hip)
+void launch_wino_input(const ConvArgs& a, float* V, const float* in_scale, const float* in_shift, bool pack, hipStream_t s);
+void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, float* M, int cfg, bool bf16x2, hipStream_t s);
+bool wino_gemm_ok_bf16x2(int Cin, int Cout);
 void launch_wino_output(const ConvArgs& a, const float* M, hipStream_t s);
 bool wino_can_fuse(int H, int W, int C, bool touches_memory);
-void launch_wino_fused(const ConvArgs& a, const float* M, float* Vnext, int feed_aff, hipStream_t s);
+void launch_wino_fused(const ConvArgs& a, const float* M, float* Vnext, int feed_aff, bool pack_next, hipStream_t s);
+void launch_pack_bf16x2(const float* in, float* out, long n, hipStream_t s);      // fp32 -> split-bf16 words, n % 4 == 0
 void wino_filter_transform(const double g[9], double u[36]);
 long wino_rows(long tiles);                  // rows per frequency plane of the V / M workspaces (tiles rounded up to 256)     // host: G g G^T of one 3x3 filter
 int conv_wt_rows(int Cout);                   // packed weight rows (Cout rounded up to 128)

@@ -27,6 +27,37 @@ namespace fh {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Split-bf16 operand format of the opt-in "bf16x2" mode (fh_rec_set_precision): a value x travels as ONE 32-bit word holding
+// hi = bf16(x) in the low half and mid = bf16(x - hi) in the high half — 16 mantissa bits, same bytes as fp32, so the V / U buffers,
+// their indexing and the GEMM's LDS-DMA loader do not change at all; only the matrix instruction does (three bf16 products
+// hh + hm + mh with f32 accumulation instead of one f32 product).
+__device__ __forceinline__ v4f wino_pack_bf16x2(const v4f x) {
+    v4u out;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const v2f a = {x[2 * p], x[2 * p + 1]};
+        const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));        // v_cvt_pk_bf16_f32 (round to nearest even)
+        const v2f r = {a[0] - __builtin_bit_cast(float, hb << 16), a[1] - __builtin_bit_cast(float, hb & 0xffff0000u)};   // exact
+        const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+        out[2 * p] = (hb & 0xffffu) | (mb << 16);
+        out[2 * p + 1] = (hb >> 16) | (mb & 0xffff0000u);
+    }
+    return __builtin_bit_cast(v4f, out);
+}
+
+__global__ __launch_bounds__(256) void pack_bf16x2_kernel(const float* __restrict__ in, float* __restrict__ out, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        *reinterpret_cast<v4f*>(out + 4 * i) = wino_pack_bf16x2(*reinterpret_cast<const v4f*>(in + 4 * i));
+}
+void launch_pack_bf16x2(const float* in, float* out, long n, hipStream_t s) {       // n % 4 == 0
+    const long n4 = n / 4;
+    if (n4 > 0) hipLaunchKernelGGL(pack_bf16x2_kernel, dim3((unsigned)std::min<long>((n4 + 255) / 256, 256 * 64)), dim3(256), 0, s, in, out, n4);
+}
 
 // B^T (6x6) applied to a 6-vector
 __device__ __forceinline__ void wino_bt(const v4f (&d)[6], v4f (&t)[6]) {
@@ -50,7 +81,7 @@ __device__ __forceinline__ void wino_at(const v4f (&m)[6], v4f (&y)[4]) {
 // producer need not write a normalised copy of its output (zero padding stays exactly zero).
 __global__ __launch_bounds__(256, 2) void wino_input_kernel(const float* __restrict__ in, float* __restrict__ V, int B, int H, int W,
                                                             int C, int TY, int TX, long NTp, const float* __restrict__ aff_s,
-                                                            const float* __restrict__ aff_t) {
+                                                            const float* __restrict__ aff_t, const int pack) {
     const int C4 = C >> 2;
     // (32-bit index arithmetic: tiles * C/4 < 2^31 is checked by the launcher; 64-bit div / mod per thread is not free)
     const int NT = B * TY * TX;
@@ -86,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void wino_input_kernel(const float* __restr
             v4f o[6];
             wino_bt(t[i], o);                                // (B^T d B)[i][j] = sum_c (B^T d)[i][c] * B^T[j][c]
 #pragma unroll
-            for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(dst + (size_t)(i * 6 + j) * fs) = o[j];
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(dst + (size_t)(i * 6 + j) * fs) = pack ? wino_pack_bf16x2(o[j]) : o[j];
         }
     }
 }
@@ -166,6 +197,7 @@ struct WinoFuseArgs {
     // (14x14, 7x7): csl4 = 16 (64 channels, whole 256-byte pixel rows per 16 lanes); up to 64 tiles (28x28 = 49): csl4 = 4 (16 channels)
     // so that the LDS image of one picture still fits.  pitch = float4 slots per pixel in LDS (5 for csl4 = 4: bank spread).
     int csl4, pitch, img;
+    int pack;               // the next convolution's GEMM takes split-bf16 operands
 };
 
 __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFuseArgs a) {
@@ -255,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFuseArgs a
         v4f o6[6];
         wino_bt(tt[i], o6);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(dst + (size_t)(i * 6 + j) * fs) = o6[j];
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(dst + (size_t)(i * 6 + j) * fs) = a.pack ? wino_pack_bf16x2(o6[j]) : o6[j];
     }
 }
 
@@ -338,6 +370,84 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __rest
             *reinterpret_cast<v4f*>(orow + j * 32 + 8 * g) = v4f{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
 }
 
+// Split-bf16 form of the same GEMM (opt-in precision mode): V and U hold (hi, mid) bf16 pairs in 32-bit words, everything up to the
+// fragment reads is byte-for-byte the f32 kernel.  A lane takes 8 consecutive k of its row per 16-deep MFMA step (two ds_read_b128),
+// separates the hi and the mid halves with v_perm_b32 and issues v_mfma_f32_32x32x16_bf16 three times: mid*hi + hi*mid + hi*hi
+// (the dropped mid*mid term is 2^-32 relative).  5x less matrix-core time per FLOP than v_mfma_f32_32x32x2_f32; the kernel is then bound
+// by the L2 -> LDS stream it shares with the f32 form.
+template <int BN, int OCC>
+__global__ __launch_bounds__(256, OCC) void wino_gemm_bf16x2_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M,
+                                                                   const int K, const int N, const int rows_per_group, const long wt_gs,
+                                                                   const int tiles_n, const int chunks) {
+    constexpr int BM = 128, TN = BN / 32, AL = BM / 32, BL = BN / 32;
+    __shared__ v4f lds[2][(BM + BN) * 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh2 = lane >> 5, fsw = (fr >> 1) & 7;
+    const int nb = gridDim.x, q = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+    const int tile = x * q + min(x, r8) + (blockIdx.x >> 3);
+    const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const float* Ug = U + (size_t)(m0 / rows_per_group) * wt_gs;
+    const int lrow = tid >> 3;
+    const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);
+    const float* a_src = V + (size_t)(m0 + lrow) * K + lqs * 4;
+    const float* b_src = Ug + (size_t)(n0 + lrow) * K + lqs * 4;
+    const size_t row32 = (size_t)32 * K;
+    v4f* const dstA = &lds[0][wid * 64];
+    v4f* const dstB = &lds[0][BM * 8 + wid * 64];
+    auto load_chunk = [&](int buf) {
+        v4f* const dA = dstA + buf * ((BM + BN) * 8);
+        v4f* const dB = dstB + buf * ((BM + BN) * 8);
+#pragma unroll
+        for (int i = 0; i < AL; ++i) wino_dma16(a_src + i * row32, dA + i * 32 * 8);
+#pragma unroll
+        for (int i = 0; i < BL; ++i) wino_dma16(b_src + i * row32, dB + i * 32 * 8);
+        a_src += 32; b_src += 32;
+    };
+    auto split = [](const v4u lo4, const v4u hi4, bf16x8& h, bf16x8& m) {       // 8 packed words -> 8 hi halves, 8 mid halves
+        const v4u hh = {__builtin_amdgcn_perm(lo4[1], lo4[0], 0x05040100u), __builtin_amdgcn_perm(lo4[3], lo4[2], 0x05040100u),
+                        __builtin_amdgcn_perm(hi4[1], hi4[0], 0x05040100u), __builtin_amdgcn_perm(hi4[3], hi4[2], 0x05040100u)};
+        const v4u mm = {__builtin_amdgcn_perm(lo4[1], lo4[0], 0x07060302u), __builtin_amdgcn_perm(lo4[3], lo4[2], 0x07060302u),
+                        __builtin_amdgcn_perm(hi4[1], hi4[0], 0x07060302u), __builtin_amdgcn_perm(hi4[3], hi4[2], 0x07060302u)};
+        h = __builtin_bit_cast(bf16x8, hh); m = __builtin_bit_cast(bf16x8, mm);
+    };
+    v16f acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    load_chunk(0);
+    __syncthreads();
+    for (int kc = 0; kc < chunks; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < chunks) load_chunk(buf ^ 1);
+        const v4u* X = reinterpret_cast<const v4u*>(lds[buf]) + (wid * 32 + fr) * 8;
+        const v4u* Wt = reinterpret_cast<const v4u*>(lds[buf]) + BM * 8 + fr * 8;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {                             // two 16-deep steps per 32-deep chunk; lane half fh2 owns k = 8*fh2 .. 8*fh2+7
+            const int c0 = (4 * ks + 2 * fh2) ^ fsw, c1 = (4 * ks + 2 * fh2 + 1) ^ fsw;
+            bf16x8 xh, xm;
+            split(X[c0], X[c1], xh, xm);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bf16x8 wh, wm;
+                split(Wt[j * 32 * 8 + c0], Wt[j * 32 * 8 + c1], wh, wm);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wm, xh, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xm, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* orow = M + (size_t)(m0 + wid * 32 + fr) * N + n0 + 4 * fh2;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<v4f*>(orow + j * 32 + 8 * g) = v4f{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+}
+
 long wino_rows(long tiles) { return (tiles + 255) / 256 * 256; }   // rows of one frequency plane: whole tiles of every GEMM configuration
 
 static inline int wino_grid(long n) {
@@ -362,7 +472,7 @@ static void wino_check(long NT, int cmax) {
 }
 
 // stage 1: in [B,H,W,Cin] -> V (optional per-channel affine on in-image pixels)
-void launch_wino_input(const ConvArgs& a, float* V, const float* in_scale, const float* in_shift, hipStream_t s) {
+void launch_wino_input(const ConvArgs& a, float* V, const float* in_scale, const float* in_shift, bool pack, hipStream_t s) {
     const int TY = (a.H + 3) / 4, TX = (a.W + 3) / 4;
     const long NT = (long)a.B * TY * TX;
     if (NT <= 0) return;
@@ -370,12 +480,15 @@ void launch_wino_input(const ConvArgs& a, float* V, const float* in_scale, const
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
     hipLaunchKernelGGL(wino_input_kernel, dim3(wino_grid(NT * (a.Cin >> 2))), dim3(256), 0, s, a.in, V, a.B, a.H, a.W, a.Cin, TY, TX, wino_rows(NT), in_scale,
-                       in_shift);
+                       in_shift, pack ? 1 : 0);
     timer.end(s, 8, 0.0, 0.0);
 }
 
 // stage 2: the 36 GEMMs  M[f] = V[f] * U[f]   (wt36 = 36 packed weight images [conv_wt_rows(Cout)][Cin])
-void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, float* M, int cfg, hipStream_t s) {
+// bf16x2: V and wt36 hold split-bf16 words (wino_gemm_ok_bf16x2 says whether this layer's GEMM has that form)
+bool wino_gemm_ok_bf16x2(int Cin, int Cout) { return Cout % 64 == 0 && Cin % 32 == 0; }
+
+void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, float* M, int cfg, bool bf16x2, hipStream_t s) {
     const int TY = (a.H + 3) / 4, TX = (a.W + 3) / 4;
     const long NT = (long)a.B * TY * TX;
     if (NT <= 0) return;
@@ -395,7 +508,11 @@ void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, floa
         const int chunks = a.Cin / 32;
         const bool wide = a.Cout % 64 == 0;
         timer.begin(s);
-        if (wide)
+        if (bf16x2) {
+            if (!wino_gemm_ok_bf16x2(a.Cin, a.Cout)) throw std::runtime_error("winograd: this layer has no split-bf16 GEMM");
+            hipLaunchKernelGGL((wino_gemm_bf16x2_kernel<64, 3>), dim3((unsigned)((rows / 128) * (a.Cout / 64))), dim3(256), 0, s, V, wt36, M, a.Cin,
+                               a.Cout, (int)NTp, g.wt_gs, a.Cout / 64, chunks);
+        } else if (wide)
             hipLaunchKernelGGL((wino_gemm_kernel<64, 3>), dim3((unsigned)((rows / 128) * (a.Cout / 64))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
                                (int)NTp, g.wt_gs, a.Cout / 64, chunks);
         else
@@ -403,6 +520,7 @@ void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, floa
                                (int)NTp, g.wt_gs, a.Cout / 32, chunks);
         timer.end(s, 7, g.t_flops, g.t_bytes);
     } else {
+        if (bf16x2) throw std::runtime_error("winograd: this layer has no split-bf16 GEMM");
         launch_conv(g, cfg, s);                              // generic grouped instantiation of conv_igemm_kernel
     }
 }
@@ -448,11 +566,11 @@ bool wino_can_fuse(int H, int W, int C, bool touches_memory) {
 
 // stage 3 of convolution `a` + stage 1 of the next one in one kernel: M -> (out1 / out2 if non-null) and -> V of the next convolution,
 // which sees out1 (feed_aff = 0) or out1 * s2 + t2 (feed_aff = 1; a.s2 / a.t2 must then be set even when a.out2 is null).
-void launch_wino_fused(const ConvArgs& a, const float* M, float* Vnext, int feed_aff, hipStream_t s) {
+void launch_wino_fused(const ConvArgs& a, const float* M, float* Vnext, int feed_aff, bool pack_next, hipStream_t s) {
     WinoFuseArgs f{};
     if (!wino_fuse_shape(a.H, a.W, a.Cout, &f.csl4, &f.pitch, &f.img)) throw std::runtime_error("winograd: this map cannot take the fused transform");
     f.o = wino_out_args(a, M);
-    f.V = Vnext; f.feed_aff = feed_aff;
+    f.V = Vnext; f.feed_aff = feed_aff; f.pack = pack_next ? 1 : 0;
     const long NT = (long)a.B * f.o.TY * f.o.TX;
     if (NT <= 0) return;
     wino_check(NT, a.Cout);
@@ -466,8 +584,8 @@ void launch_wino_fused(const ConvArgs& a, const float* M, float* Vnext, int feed
 // all three stages of one convolution (used by the single-layer test entry point)
 void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, const float* in_scale, const float* in_shift,
                           hipStream_t s) {
-    launch_wino_input(a, V, in_scale, in_shift, s);
-    launch_wino_gemm(a, wt36, V, M, cfg, s);
+    launch_wino_input(a, V, in_scale, in_shift, false, s);
+    launch_wino_gemm(a, wt36, V, M, cfg, false, s);
     launch_wino_output(a, M, s);
 }
 

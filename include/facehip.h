@@ -194,6 +194,16 @@ FH_API int fh_rec_set_winograd(fh_rec* r, int on);
 /* on (default): between two consecutive Winograd layers on a map of <= 16x16 pixels the output transform of the first and the input
  * transform of the second run as one kernel (the activation stays in LDS); off: separate transform kernels. */
 FH_API int fh_rec_set_wino_fusion(fh_rec* r, int on);
+/* Opt-in precision mode of the recogniser (the default and the headline stay fp32 = the reference's own arithmetic,
+ * src/face_recognizer.cpp:58 float tensors through onnxruntime).  FH_PREC_BF16X2: the Winograd GEMMs (the 3x3 convolutions with >= 128
+ * channels, ~80% of IResNet-50's FLOPs) take each operand as a (hi, mid) pair of bf16 — 16 mantissa bits — and run three bf16 MFMAs
+ * with f32 accumulation in place of one f32 MFMA; transforms, epilogues, all other layers and the embedding stay fp32.
+ * The call is GATED: it embeds a fixed pseudo-random batch of 64 crops in both modes and enters the mode only if every pair of
+ * embeddings agrees to 1 - cos < 1e-3; otherwise it returns FH_ERR_STATE, the handle stays fp32 and fh_last_error() quotes the measured
+ * value.  *worst (may be NULL) receives the measured max(1 - cos).  Returns the number of layers switched (>= 1), or < 0. */
+enum fh_precision { FH_PREC_FP32 = 0, FH_PREC_BF16X2 = 1 };
+FH_API int fh_rec_set_precision(fh_rec* r, int mode, float* worst);
+FH_API int fh_rec_get_precision(fh_rec* r);
 /* A handle whose stream is restricted to a subset of the CUs (hipExtStreamCreateWithCUMask, e.g. detector and
  * recogniser side by side on disjoint CU sets) should say how many it gets: it sizes the convolution kernels'
  * remainder round.  0 = the whole device (default). */

@@ -1252,3 +1252,50 @@ def test_two_streams_full_size_models_remainder_rounds():
         rt, rf, ro, re_ = ref[k]
         assert got == rt == n * F
         assert torch.equal(f[:rt].view(torch.int32), rf.view(torch.int32)) and torch.equal(o[:rt], ro) and torch.equal(e[:rt], re_)
+
+
+def test_split_bf16_mode_is_gated_and_within_tolerance(monkeypatch):
+    """Opt-in fh_rec_set_precision(FH_PREC_BF16X2) on the full-size IResNet-50 at the headline batch: the library's gate passes, the
+    embeddings stay within the north-star 1 - cos < 1e-3 of BOTH the fp32 path (all 128 slots) and the oracle's direct fp32 evaluation
+    (three slots), switching back restores the fp32 bits, and a gate the mode cannot meet leaves the handle fp32."""
+    from facerecognizeonnx_amd.synth import models
+    path = models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
+    rec = fa.FaceRecognizer(); orec = oracle.OracleRecognizer()
+    assert rec.loadModel(path) and orec.loadModel(path)
+    B = 128
+    crops = util.frames_u8(B, 112, 112, seed=4242)
+    d = dev(crops)
+
+    def embed():
+        out = torch.zeros((B, 512), device="cuda")
+        assert rec.embed_aligned_dev(d.data_ptr(), B, out.data_ptr(), 0) == B
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    f32 = embed()
+    assert rec.precision() == "fp32"
+    worst = rec.set_precision("bf16x2")
+    assert rec.precision() == "bf16x2" and 0.0 < worst < 1e-3
+    b2 = embed()
+    assert np.isfinite(b2).all() and not np.array_equal(b2, f32)           # the mode really ran something else
+    err = 1.0 - np.sum(b2.astype(np.float64) * f32.astype(np.float64), 1)
+    assert err.max() < 1e-3, err.max()
+    for i in (0, B // 2, B - 1):
+        r = oracle.run_graph(orec.g, {orec.g.inputs[0][0]: oracle.rec_preprocess(crops[i])[None]})[orec.g.outputs[0][0]].reshape(-1)
+        ref = oracle.l2_normalize(r)
+        assert 1.0 - float(np.dot(b2[i].astype(np.float64), ref.astype(np.float64))) < 1e-3
+    print(f"\n[bf16x2] gate batch max(1-cos) = {worst:.3e}; headline batch vs fp32 path = {err.max():.3e}, max |d| = {np.abs(b2 - f32).max():.3e}")
+    rec.set_precision("fp32")
+    assert rec.precision() == "fp32" and np.array_equal(embed(), f32)
+    monkeypatch.setenv("FACEHIP_PRECISION_GATE", "1e-12")                   # a bar the mode cannot meet: refused, handle stays fp32
+    with pytest.raises(RuntimeError, match="staying fp32"):
+        rec.set_precision("bf16x2")
+    assert rec.precision() == "fp32" and np.array_equal(embed(), f32)
+
+
+def test_split_bf16_mode_refused_for_a_model_without_eligible_layers(models_dir):
+    rec = fa.FaceRecognizer()
+    assert rec.loadModel(util.tiny_iresnet(models_dir, fold_bn=True))      # widest layer 64 channels: nothing runs as a Winograd GEMM
+    with pytest.raises(RuntimeError, match="no layer"):
+        rec.set_precision("bf16x2")
+    assert rec.precision() == "fp32"
