@@ -98,6 +98,7 @@ PROTOTYPES = {
     "fh_det_set_winograd": (_i, [_vp, _i]),
     "fh_rec_set_winograd": (_i, [_vp, _i]),
     "fh_rec_set_wino_fusion": (_i, [_vp, _i]),
+    "fh_rec_set_shortcut_fold": (_i, [_vp, _i]),
     "fh_rec_set_precision": (_i, [_vp, _i, C.POINTER(C.c_float)]),
     "fh_rec_get_precision": (_i, [_vp]),
     "fh_det_set_cus": (_i, [_vp, _i]),

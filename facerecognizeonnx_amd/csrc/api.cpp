@@ -574,6 +574,7 @@ int fh_rec_set_precision(fh_rec* r, int mode, float* worst_out) {
     });
 }
 int fh_rec_get_precision(fh_rec* r) { return r && r->rec.net().bf16x2() ? FH_PREC_BF16X2 : FH_PREC_FP32; }
+int fh_rec_set_shortcut_fold(fh_rec* r, int on) { if (!r) return arg_error("null handle"); r->rec.net().fold_shortcut = on != 0; return FH_OK; }
 int fh_det_set_halo_conv(fh_det* d, int on) { if (!d) return arg_error("null handle"); d->det.net().halo_conv = on != 0; return FH_OK; }
 int fh_det_set_cus(fh_det* d, int cus) { if (!d || cus < 0) return arg_error("bad argument"); d->det.net().cus = cus; return FH_OK; }
 int fh_rec_set_cus(fh_rec* r, int cus) { if (!r || cus < 0) return arg_error("bad argument"); r->rec.net().cus = cus; return FH_OK; }

@@ -180,8 +180,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
 
 // GRP: grouped form (several GEMMs stacked along M with one weight matrix each, see ConvArgs::wt_group_rows) — a separate
 // instantiation, so that the ungrouped convolutions keep their register allocation.
-template <int BM, int BN, int WM, int WN, int OCC, bool FAST, bool GRP>
-__global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const ConvArgs p, const int tiles_n, const int chunks) {
+// SC: with the folded-shortcut tap (ConvArgs::sc_in) — its own instantiation for the same reason.
+template <int BM, int BN, int WM, int WN, int OCC, bool FAST, bool GRP, bool SC = false>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const ConvArgs p_by_value, const int tiles_n, const int chunks) {
+    // The argument block is read where it already lies — the kernarg segment (constant address space, scalar loads) — instead of
+    // through the by-value parameter: clang materialises that one as a private copy which the optimiser usually removes again, and when
+    // it does not (it stopped doing so when this kernel grew the folded-shortcut tap) all 384 bytes live in scratch memory and every
+    // field access becomes a scratch load: -25 % on every convolution.
+    // (the instantiations without that tap keep the by-value form: there the copy is optimised away and the fields sit in SGPRs)
+    const ConvArgs& p = SC ? *(const ConvArgs*)__builtin_amdgcn_kernarg_segment_ptr() : p_by_value;      // first explicit argument = offset 0
     using TL = Tile<BM, BN, WM, WN>;
     constexpr int TM = TL::TM, TN = TL::TN, RP = TL::RP, AL = TL::AL, BL = TL::BL;
     __shared__ v4f lds[2][(BM + BN) * 8];
@@ -245,11 +252,12 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
         // column l&7 — the LDS image stays lane-linear and the XOR swizzle is applied to the SOURCE:
         // the lane fetches k-column (l&7) ^ ((row>>1)&7)  (cdna_hip_programming.md §5.4 rule 21).
         const float* a_ptr[AL];
+        const float* sc_ptr[AL];                            // folded shortcut (ConvArgs::sc_in): this row's pixel of the 1x1 convolution's input
         unsigned a_mask[AL];
 #pragma unroll
         for (int i = 0; i < AL; ++i) {
             const int m = m0 + lrow + i * RP;
-            a_ptr[i] = p.zeros; a_mask[i] = 0;
+            a_ptr[i] = p.zeros; a_mask[i] = 0; sc_ptr[i] = p.zeros;
             if (p.ks == 1 && p.stride == 1) {               // plain GEMM rows (1x1 convs, FC, gallery): no pixel arithmetic at all
                 if (m < M) { a_ptr[i] = p.in + (long)m * p.Cin + lqs * 4; a_mask[i] = 1u; }
             } else if (m < M) {
@@ -257,6 +265,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
                 const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
                 a_ptr[i] = p.in + (long)(((n * p.H + iy0) * p.W + ix0) * p.Cin) + lqs * 4;
+                if (SC) sc_ptr[i] = p.sc_in + (long)(((n * p.sc_H + oy * p.sc_stride) * p.sc_W + ox * p.sc_stride) * p.sc_C) + lqs * 4;
                 unsigned mk = 0;
                 if (p.ks == 3) {
 #pragma unroll
@@ -284,9 +293,23 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
         int ld_tap = 0, ld_ci = 0;
         const float* cur[AL];
         int adv[AL];                                        // floats a row's pointer advances per chunk: 32, or 0 while it reads the zero line
-        auto tap_setup = [&]() {                            // (a dead row of the 25 088-deep FC would otherwise walk 100 KB past the 8 KiB of zeros)
+        // (loop-carried uses of the argument block go through locals: `p` lives in memory and every barrier / asm memory clobber in
+        //  the K loop would otherwise re-fetch the field — an s_load + lgkmcnt wait per chunk)
+        const int Cin = p.Cin, ksz = p.ks, inW = p.W;
+        const int taps = ksz * ksz;
+        auto tap_setup = [&]() __attribute__((always_inline)) {                            // (a dead row of the 25 088-deep FC would otherwise walk 100 KB past the 8 KiB of zeros)
+            if (ld_tap >= taps) {                           // past the own taps: the folded shortcut's pixels (ConvArgs::sc_in)
+                if (!SC) return;
+#pragma unroll
+                for (int i = 0; i < AL; ++i) {
+                    const bool on = a_mask[i] != 0;
+                    cur[i] = (const float*)(on ? (unsigned long long)(sc_ptr[i] + ld_ci) : zero_addr);
+                    adv[i] = on ? 32 : 0;
+                }
+                return;
+            }
             const int ky = ld_tap / 3, kx = ld_tap - ky * 3;
-            const int toff = (p.ks == 3 ? (ky * p.W + kx) * p.Cin : 0) + ld_ci;
+            const int toff = (ksz == 3 ? (ky * inW + kx) * Cin : 0) + ld_ci;
 #pragma unroll
             for (int i = 0; i < AL; ++i) {
                 const unsigned long long real = (unsigned long long)(a_ptr[i] + toff);
@@ -296,11 +319,11 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
             }
         };
         if (FAST) {
-            ld_tap = (c_begin * 32) / p.Cin;
-            ld_ci = c_begin * 32 - ld_tap * p.Cin;
+            ld_tap = min((c_begin * 32) / Cin, taps);
+            ld_ci = c_begin * 32 - ld_tap * Cin;
             tap_setup();
         }
-        auto load_chunk = [&](int kc, int buf) {
+        auto load_chunk = [&](int kc, int buf) __attribute__((always_inline)) {
             v4f* const dA = dstA + buf * ((BM + BN) * 8);
             v4f* const dB = dstB + buf * ((BM + BN) * 8);
             if (FAST) {
@@ -310,18 +333,18 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                 for (int i = 0; i < BL; ++i) lds_dma16(reinterpret_cast<const float*>(w_base + w_off[i]), dB + i * RP * 8);
                 w_base += 128;
                 ld_ci += 32;
-                if (ld_ci >= p.Cin) { ld_ci = 0; ++ld_tap; tap_setup(); }      // wave-uniform branch
+                if (ld_ci >= Cin && ld_tap < taps) { ld_ci = 0; ++ld_tap; tap_setup(); }      // wave-uniform branch
                 return;
             }
             const int kb = kc * 32;
             int tap, toff;                               // toff: float offset of this lane's 4 channels from a_ptr
-            if (p.ks == 1) { tap = 0; toff = kb; }
+            if (ksz == 1) { tap = 0; toff = kb; }
             else {
                 const int k4 = kb + lqs * 4;
-                tap = k4 / p.Cin;
-                const int ci = k4 - tap * p.Cin;
+                tap = k4 / Cin;
+                const int ci = k4 - tap * Cin;
                 const int ky = tap / 3, kx = tap - ky * 3;
-                toff = (ky * p.W + kx) * p.Cin + ci - lqs * 4;
+                toff = (ky * inW + kx) * Cin + ci - lqs * 4;
             }
             const bool kvalid = kb + lqs * 4 < Ktot;
 #pragma unroll
@@ -598,7 +621,9 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
     const dim3 grid((unsigned)(full + helpers + owners));
     if (grouped) {                                             // (wt_group_rows % BM == 0 and Cin % 32 == 0: the caller's contract)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true, true>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
-    } else if ((a.Cin & 31) == 0)
+    } else if (a.sc_in)                                        // (launch_conv checked Cin % 32 == 0)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true, false, true>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
+    else if ((a.Cin & 31) == 0)
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, true, false>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
     else
         hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, OCC, false, false>), grid, dim3(WM * WN * 64), 0, s, a, tiles_n, chunks);
@@ -616,6 +641,9 @@ void launch_conv(const ConvArgs& a, int cfg, hipStream_t s) {
     // the loader and the epilogue index pixels and tensor elements with 32-bit integers
     if ((long)a.B * a.H * a.W * a.Cin >= (1L << 31) || M * a.Cout >= (1L << 31))
         throw std::runtime_error("conv: tensor too large for the 32-bit element offsets of one launch (split the batch)");
+    if (a.sc_in && (a.ks != 3 || a.Cin % 32 != 0 || a.sc_C % 32 != 0 || a.Kpad != 9 * a.Cin + a.sc_C || a.wt_group_rows > 0 ||
+                    (long)a.B * a.sc_H * a.sc_W * a.sc_C >= (1L << 31)))
+        throw std::runtime_error("conv: folded shortcut needs a 3x3 convolution with Cin % 32 == 0, sc_C % 32 == 0 and Kpad = 9*Cin + sc_C");
     if (cfg < 0) cfg = conv_pick_cfg(M, a.Cout);
     switch (cfg) {
         case 0: launch_cfg<128, 128, 2, 2, 2>(a, 2, 0, s); break;

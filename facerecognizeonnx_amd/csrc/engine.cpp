@@ -192,6 +192,24 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
         if (!op.slope.empty()) { d.slope = push(op.slope.data(), op.slope.size()); d.has_slope = true; }
         if (!op.s2.empty()) { d.s2 = push(op.s2.data(), op.s2.size()); d.t2 = push(op.t2.data(), op.t2.size()); d.has_aff = true; }
     }
+    // A strided IResNet block: the 1x1 shortcut runs inside the K loop of the 3x3 convolution it is added to (POp::sc_src)
+    for (size_t i = 0; i < plan_.ops.size(); ++i) {
+        const POp& c = plan_.ops[i];
+        if (c.sc_src < 0 || dev_[i].bn_fold_src >= 0 || c.bias.size() != (size_t)c.Cout) continue;
+        const POp& x = plan_.ops[c.sc_src];
+        const int K9 = 9 * c.Cin, K = K9 + x.Cin, rows = conv_wt_rows(c.Cout);
+        std::vector<float> w((size_t)rows * K, 0.f), b((size_t)c.Cout);
+        for (int co = 0; co < c.Cout; ++co) {
+            std::copy_n(&c.weight[(size_t)co * K9], K9, &w[(size_t)co * K]);
+            std::copy_n(&x.weight[(size_t)co * x.Cin], x.Cin, &w[(size_t)co * K + K9]);
+            b[co] = c.bias[co] + (x.bias.empty() ? 0.f : x.bias[co]);
+        }
+        dev_[i].wt_sc = push(w.data(), w.size());
+        dev_[i].bias_sc = push(b.data(), b.size());
+        dev_[i].Kpad_sc = K;
+        dev_[i].sc_src = c.sc_src;
+        dev_[c.sc_src].sc_dst = true;
+    }
     // A Winograd conv that is the only reader of its producer's BatchNorm'ed second output takes the producer's plain output
     // instead and lets its input transform apply the affine (exact: padding stays zero): the second output is never written.
     // The planner finds these pairs (POp::bn_src) and keeps the plain output alive up to the consumer.
@@ -352,6 +370,7 @@ void Net::run(int batch, hipStream_t s, int first_op) {
         switch (op.kind) {
             case OpKind::CONV:
             case OpKind::GEMM: {
+                if (d.sc_dst && fold_shortcut && force_cfg < 0) break;   // runs inside its consumer's K loop
                 ConvArgs a{};
                 a.in = tensor_ptr(op.in);
                 a.wt = P + d.wt;
@@ -381,6 +400,13 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 int cfg = force_cfg >= 0 ? force_cfg : conv_pick_cfg(M, op.Cout);
                 if (force_cfg < 0 && cfg == 0 && ((M + 127) / 128) * ((op.Cout + 127) / 128) < 128) cfg = 3;   // very few tiles: go finer
                 a.t_flops = 2.0 * op.macs * batch; a.t_bytes = op.bytes * batch;
+                if (d.sc_src >= 0 && fold_shortcut && force_cfg < 0) {
+                    const POp& x = plan_.ops[d.sc_src];
+                    a.wt = P + d.wt_sc; a.bias = P + d.bias_sc; a.Kpad = d.Kpad_sc;
+                    a.res = nullptr; a.res_mode = (int)ResMode::NONE;
+                    a.sc_in = tensor_ptr(x.in); a.sc_H = x.H; a.sc_W = x.W; a.sc_C = x.Cin; a.sc_stride = x.stride;
+                    a.t_flops += 2.0 * x.macs * batch;
+                }
                 // (small batches: the 36 GEMMs would be mostly tile padding and the direct form with split-K is faster —
                 //  measured cross-over at 256 tiles per GEMM: B = 1: 0.98 ms direct / 1.83 ms Winograd, B = 32: 4.82 / 3.88)
                 if (d.halo && halo_conv && force_cfg < 0) {

@@ -45,6 +45,7 @@ class Net {
     int capacity() const { return cap_; }
     bool winograd = true;                                 // Winograd F(4x4,3x3) for the deep 3x3 convs (false: direct form everywhere)
     bool halo_conv = true;                                // tuning / test hook: spatial-tile kernel for the thin 3x3 convolutions
+    bool fold_shortcut = true;                            // tuning / test hook: a block's strided 1x1 shortcut as a tenth tap of the 3x3 it is added to
     bool fuse_wino = true;                                // tuning / test hook: fused output+input transform between consecutive Winograd layers
     // opt-in precision mode (fh_rec_set_precision): the Winograd GEMMs take split-bf16 operands (hi + mid bf16 per value, three bf16 MFMAs,
     // f32 accumulate); transforms, epilogues and every other layer stay fp32.  Returns the number of layers that switch.
@@ -73,6 +74,10 @@ class Net {
         int bn_fold_src = -1;                                 // direct 3x3 conv with its block's BatchNorm folded in (weights * s, 9-class bias):
                                                               // reads op[bn_fold_src].out, whose second output is then never written
         bool bn_fold_dst = false;                             // ... and the producer's side: skip out2
+        int sc_src = -1;                                      // 3x3 conv that can take op[sc_src] (1x1 shortcut) into its K loop ...
+        size_t wt_sc = 0, bias_sc = 0;                        // ... weights [rows][9*Cin + sc_C] and summed bias for that form
+        int Kpad_sc = 0;
+        bool sc_dst = false;                                  // ... and the shortcut's side: skipped when its consumer folds it
         bool fuse_next = false;                               // Winograd op followed by another on the same small map: fused transform kernel
         bool fuse_feed_aff = false;                           //   the next conv sees out * s2 + t2 (its block's BatchNorm) instead of out
         bool fuse_keep_out1 = true;                           //   something else reads the plain output too (e.g. a later residual): write it

@@ -54,6 +54,11 @@ struct ConvArgs {
     int ks, stride, pad;
     int Kpad;               // multiple of 32
     int bias_cls;           // see bias
+    // folded shortcut (sc_in != null; needs ks == 3, Cin % 32 == 0, sc_C % 32 == 0): a 1x1 stride-sc_stride convolution of sc_in
+    // [B,sc_H,sc_W,sc_C] on the same output grid runs as a tenth tap of the K loop — wt holds its sc_C columns after the 9*Cin
+    // own ones (Kpad = 9*Cin + sc_C), bias the sum of both biases
+    const float* sc_in;
+    int sc_H, sc_W, sc_C, sc_stride;
     int act;                // fh::Act
     int res_mode;           // fh::ResMode
     const float* dw_w;      // fused depthwise 3x3 front end (launch_dwpw): weights [9][Cin], bias [Cin], activation

@@ -789,6 +789,26 @@ static Plan build_plan_impl(const OnnxModel& m, int inH, int inW) {
         PTensor& plain = P.tensors[P.ops[prod].out];
         plain.last = std::max(plain.last, (int)i);
     }
+    // Shortcut-in-the-K-loop links (POp::sc_src)
+    for (size_t i = 0; i < P.ops.size(); ++i) {
+        POp& c = P.ops[i];
+        if (c.kind != OpKind::CONV || c.ks != 3 || c.res < 0 || c.res_mode != ResMode::SAME || c.act != Act::NONE || !c.outs.empty() ||
+            c.Cin % 32 != 0) continue;
+        int uses = 0, prod = -1;
+        for (size_t j = 0; j < P.ops.size(); ++j) {
+            const POp& o = P.ops[j];
+            for (int x : {o.in, o.in2, o.res}) if (x == c.res) ++uses;
+            if (o.out == c.res && j < i) prod = (int)j;
+        }
+        for (const auto& o : P.outputs) if (o.tensor == c.res) ++uses;
+        if (prod < 0 || uses != 1) continue;
+        const POp& x = P.ops[prod];
+        if (x.kind != OpKind::CONV || x.ks != 1 || x.pad != 0 || x.act != Act::NONE || x.out2 >= 0 || x.res >= 0 || !x.outs.empty() ||
+            x.Cin % 32 != 0 || x.Cout != c.Cout || x.Ho != c.Ho || x.Wo != c.Wo || x.in < 0) continue;
+        c.sc_src = prod;
+        PTensor& src = P.tensors[x.in];
+        src.last = std::max(src.last, (int)i);
+    }
     const int nops = (int)P.ops.size();
     for (auto& t : P.tensors) {
         if (t.is_input) t.first = 0;
@@ -848,6 +868,7 @@ std::string Plan::describe() const {
         if (o.res >= 0) os << (o.res_mode == ResMode::UP2X ? " +res(up2x)" : " +res");
         if (o.out2 >= 0) os << (o.out >= 0 ? " +bn2nd" : " bn2nd-only");
         if (o.bn_src >= 0) os << " bn<-op" << o.bn_src;
+        if (o.sc_src >= 0) os << " sc<-op" << o.sc_src;
         os << "  [in t" << o.in << " out t" << o.out << " out2 t" << o.out2 << "]";
         os << "  MMAC " << o.macs * 1e-6 << "\n";
     }

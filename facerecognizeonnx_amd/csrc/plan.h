@@ -56,6 +56,10 @@ struct POp {
     // the engine's Winograd input transform may read op[bn_src].out instead and apply s2 / t2 itself (exact: padding stays
     // zero), so that the second output is never written.  The planner keeps op[bn_src].out alive up to this op for that.
     int bn_src = -1;
+    // 3x3 CONV (no activation) whose residual is the output of op[sc_src], a 1x1 convolution with no other reader (an IResNet block's
+    // strided shortcut): the engine may run the shortcut as a tenth tap of this op's K loop (weights concatenated along K, biases
+    // summed) and skip op[sc_src].  The planner keeps op[sc_src]'s INPUT alive up to this op for that.
+    int sc_src = -1;
     double macs = 0;                  // multiply-accumulates per image
     double bytes = 0;                 // algorithmic activation bytes per image (in + res + outs)
 };

@@ -194,6 +194,9 @@ FH_API int fh_rec_set_winograd(fh_rec* r, int on);
 /* on (default): between two consecutive Winograd layers on a map of <= 16x16 pixels the output transform of the first and the input
  * transform of the second run as one kernel (the activation stays in LDS); off: separate transform kernels. */
 FH_API int fh_rec_set_wino_fusion(fh_rec* r, int on);
+/* on (default): the strided 1x1 shortcut convolution of an IResNet block runs as a tenth tap inside the K loop of the 3x3 convolution
+ * it is added to (weights concatenated along K, one launch, no residual round trip); off: two convolutions + residual add. */
+FH_API int fh_rec_set_shortcut_fold(fh_rec* r, int on);
 /* Opt-in precision mode of the recogniser (the default and the headline stay fp32 = the reference's own arithmetic,
  * src/face_recognizer.cpp:58 float tensors through onnxruntime).  FH_PREC_BF16X2: the Winograd GEMMs (the 3x3 convolutions with >= 128
  * channels, ~80% of IResNet-50's FLOPs) take each operand as a (hi, mid) pair of bf16 — 16 mantissa bits — and run three bf16 MFMAs

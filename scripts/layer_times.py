@@ -25,7 +25,11 @@ else:
     data = torch.from_numpy(rng.integers(0, 256, (B, 640, 640, 3), dtype=np.uint8)).cuda()
     run = lambda: L.fh_det_run_network_dev(net.handle, data.data_ptr(), B, 640, 640, 1920, 640 * 1920, 0)
     desc = fa.plan_describe(path, 640, 640)
+import re
 ops = [l for l in desc.splitlines()[1:] if l and l[0].isdigit()]
+folded = {int(m.group(1)) for l in ops for m in [re.search(r"sc<-op(\d+)", l)] if m}      # shortcuts that run inside their consumer
+if os.environ.get("FACEHIP_NO_SC_FOLD") != "1":
+    ops = [l for l in ops if int(l.split()[0]) not in folded]
 for _ in range(3): run()
 torch.cuda.synchronize()
 L.fh_timing_enable(1)

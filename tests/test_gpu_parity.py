@@ -1299,3 +1299,29 @@ def test_split_bf16_mode_refused_for_a_model_without_eligible_layers(models_dir)
     with pytest.raises(RuntimeError, match="no layer"):
         rec.set_precision("bf16x2")
     assert rec.precision() == "fp32"
+
+
+@pytest.mark.parametrize("ds_first", [False, True])
+def test_folded_shortcut_matches_oracle_and_the_two_conv_form(tmp_path, ds_first):
+    """A strided IResNet block's 1x1 shortcut as a tenth tap of the 3x3 convolution it is added to (engine: POp::sc_src,
+    conv_mfma.hip tap_setup) — raw outputs against the oracle and against the library's own two-convolution form, with the shortcut
+    written before and after the block's convolutions (arena liveness of the shortcut's input)."""
+    from facerecognizeonnx_amd.synth import models
+    path = models.make_iresnet(str(tmp_path / f"sc_{int(ds_first)}.onnx"), (1, 2, 1, 1), (32, 64, 128, 128), 112, 64, seed=9, downsample_first=ds_first)
+    assert fa.plan_describe(path, 112, 112).count("sc<-op") == 4
+    rec = fa.FaceRecognizer(); orec = oracle.OracleRecognizer()
+    assert rec.loadModel(path) and orec.loadModel(path)
+    n = 5                                                                # 5 x 56 x 56 rows: partial last tile + stream-K remainder
+    crops = util.frames_u8(n, 112, 112, seed=31)
+    got = {}
+    for fold in (1, 0):
+        assert fa.lib().fh_rec_set_shortcut_fold(rec.handle, fold) == 0
+        out = torch.zeros((n, 64), device="cuda"); raw = torch.zeros((n, 64), device="cuda")
+        assert rec.embed_aligned_dev(dev(crops).data_ptr(), n, out.data_ptr(), raw.data_ptr()) == n
+        torch.cuda.synchronize()
+        got[fold] = raw.cpu().numpy()
+    assert not np.array_equal(got[0], got[1])                             # different summation order: really two code paths
+    for i in range(n):
+        r = oracle.run_graph(orec.g, {orec.g.inputs[0][0]: oracle.rec_preprocess(crops[i])[None]})[orec.g.outputs[0][0]].reshape(-1)
+        for fold in (1, 0):
+            np.testing.assert_allclose(got[fold][i], r, rtol=1e-4, atol=1e-4 * np.abs(r).max(), err_msg=f"fold={fold} slot {i}")

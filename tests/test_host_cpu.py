@@ -262,3 +262,29 @@ def test_planner_keeps_plain_output_alive_for_the_winograd_bn_link(tmp_path):
                 assert o2 + e2 <= off or off + elems <= o2, (plain, t)
         links += shortcut_between
     assert links >= 3                                                  # the stage-opening blocks: shortcut conv sits between
+
+
+@pytest.mark.parametrize("ds_first", [False, True])
+def test_planner_keeps_the_shortcut_input_alive_for_the_folded_form(tmp_path, ds_first):
+    """POp::sc_src: a strided block's 3x3 convolution may run the 1x1 shortcut inside its own K loop, i.e. read the SHORTCUT's input
+    at its own position — which the op list does not show when the shortcut comes first.  That tensor must stay live and un-aliased."""
+    path = models.make_iresnet(str(tmp_path / f"sc_{int(ds_first)}.onnx"), (1, 2, 1, 1), (32, 64, 128, 128), 112, 64, seed=9, downsample_first=ds_first)
+    desc = fa.plan_describe(path, 112, 112)
+    ops = [l for l in desc.splitlines() if re.match(r"^\d+ ", l)]
+    tens = {int(m.group(1)): (int(m.group(2)) * int(m.group(3)) * int(m.group(4)), int(m.group(5)), int(m.group(6)), int(m.group(7)))
+            for m in re.finditer(r"tensor t(\d+) (\d+)x(\d+)x(\d+) off (\d+) live (-?\d+)\.\.(-?\d+)", desc)}
+    links = 0
+    for l in ops:
+        m = re.search(r"sc<-op(\d+)", l)
+        if not m:
+            continue
+        i, sc = int(l.split()[0]), int(m.group(1))
+        assert " k3s2 " in l and "+res" in l and " k1s2 " in ops[sc]
+        src = int(re.search(r"\[in t(-?\d+)", ops[sc]).group(1))
+        elems, off, first, last = tens[src]
+        assert last >= i, (l, tens[src])
+        for t, (e2, o2, f2, l2) in tens.items():
+            if t != src and not (l2 < first or last < f2):
+                assert o2 + e2 <= off or off + elems <= o2, (src, t)
+        links += 1
+    assert links == 4                                                  # one per stage
