@@ -16,11 +16,13 @@
 // layers are bandwidth-bound and >= 2 workgroups per CU overlap each other's phases.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstring>
 #include <stdexcept>
+#include <type_traits>
 
 #include "kernels.h"
 #include "plan.h"
-#include "stem_fma.h"
 
 namespace fh {
 
@@ -46,10 +48,9 @@ constexpr int DP_HW = DP_TW + 2, DP_HALO = (DP_TH + 2) * DP_HW;         // 10 x 
 // flight per CU) and the halo barrier disappears; it is the only form for DS == 2, whose 17 x 33 halo would not fit.
 // HC = 16-byte channel columns per pixel handled at a time: 8 (a 32-channel chunk), or 4 for layers with C <= 16 —
 // half the halo LDS, so more workgroups per CU, and no idle depthwise lanes.
-template <int BN, int WM, int WN, int DS, int HC, bool DIRECT, bool STEM = false>
+template <int BN, int WM, int WN, int DS, int HC, bool DIRECT>
 __global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2) : HC == 4 ? 4 : 2) void dwpw_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_n) {
     static_assert(DS == 1 || DIRECT, "stride 2 needs the direct form");
-    static_assert(!STEM || (HC == 4 && !DIRECT && DP_HALO <= 256), "the fused stem produces a 16-channel halo, one pixel per thread");
     constexpr int BM = DP_BM;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int HALO_SLOTS = !DIRECT ? (DP_HALO * HC + 255) / 256 * 256 : 0;  // float4 slots, whole DMA passes
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2)
     const int n = t / tiles_y;
     const int n0 = tile_n * BN;
     const int chunks = p.Kpad / 32;
-    const float* img = STEM ? nullptr : p.in + (size_t)n * p.H * p.W * C;  // H x W = depthwise input, Ho x Wo = output grid
+    const float* img = p.in + (size_t)n * p.H * p.W * C;  // H x W = depthwise input, Ho x Wo = output grid
 
     // ---- halo loader: slot s = 256*j + tid covers halo pixel s>>3, 16-byte column s&7
     constexpr int HP = !DIRECT ? HALO_SLOTS / 256 : 1;
@@ -121,78 +122,7 @@ __global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2)
         const bool hvalid = c0 + hq * 4 < C;                               // 16-byte columns past C are never read: no DMA for them
         const int ksteps = min(4, (C - c0 + 7) >> 3);                      // 8-deep MFMA steps that hold real channels
         __syncthreads();                                                   // previous chunk: halo + fragments fully consumed
-        if (STEM) {
-            // halo pixel tid of the tile = one output pixel of the stem convolution, computed here from the u8 frame (3 aligned dwords per
-            // image row, weights in SGPRs: see stem_conv_px_kernel in ops_misc.hip); pixels outside the map are the depthwise zero padding
-            if (tid < DP_HALO) {
-                const int hy = tid / DP_HW, hx = tid - hy * DP_HW;
-                const int ay = ty0 + hy - 1, ax = tx0 + hx - 1;
-                float a16[16];
-#pragma unroll
-                for (int c = 0; c < 16; ++c) a16[c] = 0.f;
-                if ((unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W) {
-                    const int S = p.u8_stride;
-                    const int iy0 = ay * S - 1, ix0 = ax * S - 1;
-                    const uint8_t* frame = p.u8_src + (size_t)n * p.u8_img_stride;
-                    float v[27];
-                    if (iy0 >= 0 && iy0 + 2 < p.u8_srcH && ix0 >= 1 && ix0 + 2 <= p.u8_srcW - 2) {
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) {
-                            const unsigned long long a = (unsigned long long)(frame + (size_t)(iy0 + r) * p.u8_step + (size_t)ix0 * 3);
-                            const unsigned sh = (unsigned)a & 3u;
-                            const dwpw_gmem_u32* q = (const dwpw_gmem_u32*)(a - sh);
-                            const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
-                            const unsigned n0 = __builtin_amdgcn_alignbyte(d1, d0, sh), n1 = __builtin_amdgcn_alignbyte(d2, d1, sh), n2 = d2 >> (8u * sh);
-                            v[r * 9 + 0] = (float)(n0 & 255u); v[r * 9 + 1] = (float)((n0 >> 8) & 255u); v[r * 9 + 2] = (float)((n0 >> 16) & 255u); v[r * 9 + 3] = (float)(n0 >> 24);
-                            v[r * 9 + 4] = (float)(n1 & 255u); v[r * 9 + 5] = (float)((n1 >> 8) & 255u); v[r * 9 + 6] = (float)((n1 >> 16) & 255u); v[r * 9 + 7] = (float)(n1 >> 24);
-                            v[r * 9 + 8] = (float)(n2 & 255u);
-                        }
-                    } else {
-                        // window touches the frame's border: per tap — outside the net input = conv zero padding (127.5 cancels against the
-                        // folded bias), inside it but outside the pasted image = letterbox canvas (u8 0)
-#pragma unroll
-                        for (int r = 0; r < 3; ++r)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const int iy = iy0 + r, ix = ix0 + c;
-                                float b0 = 127.5f, b1 = 127.5f, b2 = 127.5f;
-                                if ((unsigned)iy < (unsigned)p.u8_inH && (unsigned)ix < (unsigned)p.u8_inW) {
-                                    b0 = b1 = b2 = 0.f;
-                                    if (iy < p.u8_srcH && ix < p.u8_srcW) {
-                                        const uint8_t* px = frame + (size_t)iy * p.u8_step + (size_t)ix * 3;
-                                        b0 = (float)px[0]; b1 = (float)px[1]; b2 = (float)px[2];
-                                    }
-                                }
-                                v[r * 9 + c * 3 + 0] = b0; v[r * 9 + c * 3 + 1] = b1; v[r * 9 + c * 3 + 2] = b2;
-                            }
-                    }
-                    fh_v2f a2[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) a2[i] = fh_v2f{p.stem_bf[2 * i], p.stem_bf[2 * i + 1]};
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const float* wrow = p.stem_wf + (size_t)(r * 9) * 16;
-                        fh_v2f xp[5];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) xp[i] = fh_v2f{v[r * 9 + 2 * i], v[r * 9 + 2 * i + 1]};
-                        xp[4] = fh_v2f{v[r * 9 + 8], 0.f};
-#if defined(__HIP_DEVICE_COMPILE__)
-                        FH_STEM_ROW_FMA(a2, xp, wrow, 64);
-#else
-                        (void)wrow; (void)xp;
-#endif
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { a16[2 * i] = a2[i][0]; a16[2 * i + 1] = a2[i][1]; }
-                    if (p.stem_act == (int)Act::RELU) {
-#pragma unroll
-                        for (int c = 0; c < 16; ++c) a16[c] = a16[c] > 0.f ? a16[c] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) halo[tid * 4 + q] = v4f{a16[4 * q], a16[4 * q + 1], a16[4 * q + 2], a16[4 * q + 3]};
-            }
-        } else if (!DIRECT && hvalid) {
+        if (!DIRECT && hvalid) {
 #pragma unroll
             for (int j = 0; j < HP; ++j) {
                 const float* src = h_off[j] >= 0 ? img + h_off[j] + c0 : p.zeros;
@@ -334,10 +264,7 @@ static void launch_dwpw_cfg(const ConvArgs& a, hipStream_t s) {
     const dim3 grid((unsigned)(a.B * tiles_y * tiles_x * tiles_n));
     // (the direct form was measured for stride 1 too: 15-20 % slower than the LDS halo on every SCRFD layer —
     //  L1 traffic of the 4.5-6x re-reads costs more than the extra loads in flight gain)
-    if (a.u8_src) {
-        if (a.Cin != 16 || a.dw_stride != 1 || BN > 64) throw std::runtime_error("dwpw: the fused stem needs 16 channels, stride 1 and Cout <= 64");
-        hipLaunchKernelGGL((dwpw_kernel<(BN <= 64 ? BN : 64), (BN <= 64 ? WM : 2), (BN <= 64 ? WN : 2), 1, 4, false, true>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
-    } else if (a.dw_stride == 2 && a.Cin <= 16 && BN <= 64)     // 16 channels = 4 float4 columns: every depthwise lane busy, 2-row strips (fewer registers)
+    if (a.dw_stride == 2 && a.Cin <= 16 && BN <= 64)     // 16 channels = 4 float4 columns: every depthwise lane busy, 2-row strips (fewer registers)
         hipLaunchKernelGGL((dwpw_kernel<(BN <= 64 ? BN : 64), (BN <= 64 ? WM : 2), (BN <= 64 ? WN : 2), 2, 4, true>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
     else if (a.dw_stride == 2) hipLaunchKernelGGL((dwpw_kernel<BN, WM, WN, 2, 8, true>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
     else if (a.Cin <= 16 && BN <= 64) hipLaunchKernelGGL((dwpw_kernel<(BN <= 64 ? BN : 64), (BN <= 64 ? WM : 2), (BN <= 64 ? WN : 2), 1, 4, false>), grid, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_n);
@@ -346,13 +273,338 @@ static void launch_dwpw_cfg(const ConvArgs& a, hipStream_t s) {
 
 // a.in = depthwise input [B,H,W,C] (a.dw_stride 1 | 2, pad 1; Ho x Wo = its output grid = the pointwise grid), a.Cin = C, a.wt = packed pointwise weights
 // [..][conv_kpad(C)], a.dw_w [9][C], a.dw_b [C]; activation of the pointwise part limited to NONE / RELU.
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// SCRFD's opening block in ONE persistent kernel: u8 frame -> stem 3x3 (3 -> 16 channels, stride 1 | 2, preprocess folded into the
+// weights) -> depthwise 3x3 -> pointwise 1x1 (16 -> Cout <= 32).  The stem's 16-channel map — the largest tensor of the network — is
+// never written.  A tile (8 x 16 outputs) is a chain of four short phases; run as one workgroup per tile that chain is latency, not
+// bandwidth (measured: 6.8 us per tile, 4 workgroups per CU, 0.68 ms for 128 frames while moving 1 GB).  So the workgroups are
+// persistent: weights, biases and MFMA fragments are fetched once, and the only global read of a tile — its u8 window — is issued one
+// tile AHEAD into registers, so that no phase of the loop waits on memory:
+//   1. the prefetched u8 window (9S+3 rows x (17S+3) pixels, as aligned dwords) goes registers -> LDS; the next tile's loads are issued
+//   2. stem on the matrix cores, v_mfma_f32_16x16x32_bf16: rows = 16 output channels (A = weights), columns = 16 halo pixels (B),
+//      K = the 27 taps of the 3 x 9-byte window (+5 zeros).  u8 values (and the 127.5 of the conv padding) are exact in bf16, every
+//      fp32 weight travels as three bf16 terms (hi + mid + lo = w exactly: stem_pack_wfrag), every product is exact in fp32 and the
+//      accumulator is fp32: the fp32 FMA chain's value up to summation order, at a tenth of its vector instructions.
+//      Lane l of a group: pixel l & 15, K block g = l >> 4 (g < 3: bytes 0..7 of window row g; g = 3: byte 8 of rows 0..2); the result
+//      comes back as pixel l & 15, channels 4g..4g+3 = one 16-byte column of the halo image [180 pixels][16 channels].
+//   3. depthwise 3x3 from the halo image (vector ALU, 4 channels per lane) -> A tile [128 pixels][32 k], XOR-swizzled
+//   4. pointwise product on v_mfma_f32_32x32x2_f32 (K = 16), bias + ReLU, stores.
+// Three barriers per tile.  Tiles are dealt so that the workgroups of one XCD work on neighbouring tiles at the same time (shared
+// window rows hit that XCD's L2).
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Folded stem weights wf [27][16] (tap-major: (ky*9 + kx*3 + byte) x channel) as the A fragments of v_mfma_f32_16x16x32_bf16: three
+// bf16 terms (hi, mid, lo — their sum is the fp32 weight exactly), lane l = channel l & 15, K block l >> 4; K index 8g + j = byte j of
+// window row g (g < 3), 24 + r = byte 8 of row r, 27..31 = 0.  out: [3][64][4] dwords.
+void stem_pack_wfrag(const float* wf, unsigned* out) {
+    auto bf = [](float x) {                                                // round to nearest even, as bits
+        unsigned u; memcpy(&u, &x, 4);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return u >> 16;
+    };
+    auto fl = [](unsigned b) { unsigned u = b << 16; float x; memcpy(&x, &u, 4); return x; };
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < 8; ++j) {
+            const int co = l & 15, k = 8 * (l >> 4) + j;
+            float w = 0.f;
+            if (k < 24) w = wf[((k >> 3) * 9 + (k & 7)) * 16 + co];
+            else if (k < 27) w = wf[((k - 24) * 9 + 8) * 16 + co];
+            const unsigned hi = bf(w); const float r1 = w - fl(hi);
+            const unsigned mid = bf(r1); const float r2 = r1 - fl(mid);
+            const unsigned t[3] = {hi, mid, bf(r2)};
+            for (int q = 0; q < 3; ++q) {
+                unsigned& d = out[(q * 64 + l) * 4 + (j >> 1)];
+                d = (j & 1) ? (d | (t[q] << 16)) : t[q];
+            }
+        }
+}
+
+constexpr int FR_PITCH = 32;                                               // dwords per staged u8 row: (17*2+3)*3 + 3 bytes <= 128
+constexpr int FR_ROWS = 21;                                                // 9*2 + 3
+constexpr int FR_SLOTS = (FR_ROWS * FR_PITCH + 255) / 256;                 // staged dwords per thread (3)
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would make every barrier of the tile loop
+// wait for the NEXT tile's window loads
+__device__ __forceinline__ void front_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// STEP4: the frames' row pitch is a multiple of 4 — the misalignment of a staged row is then the same for every row of a tile (one
+// scalar) instead of a per-row value.
+template <bool STEP4>
+__global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_total) {
+    __shared__ unsigned stage[2][FR_ROWS * FR_PITCH];
+    __shared__ v4f halo[192 * 4];
+    __shared__ v4f At[DP_BM * 8];
+    __shared__ v4f Wt[32 * 8];
+    __shared__ v4f cst[48];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = p.u8_stride, step = p.u8_step;
+    const int nrows = 9 * S + 3;
+    const int row_bytes = p.u8_srcW * 3;
+
+    // ---- once per workgroup: pointwise weights -> LDS, depthwise weights / biases -> LDS, stem fragments -> registers
+    {
+        const int lrow = tid >> 3, lqs = (tid & 7) ^ ((lrow >> 1) & 7);
+        dwpw_dma16(p.wt + (size_t)lrow * p.Kpad + lqs * 4, Wt + wid * 64);
+    }
+    const int dq = tid & 3, dp = tid >> 2;                                 // depthwise: 16-byte column dq of pixels dp, dp + 64
+    // depthwise weights [9][16], depthwise bias [16], pointwise bias [32] live in LDS (re-read per tile) — in registers they would push
+    // the kernel past the 128 VGPRs that 4 workgroups per CU allow
+    if (tid < 36) cst[tid] = *reinterpret_cast<const v4f*>(p.dw_w + tid * 4);
+    else if (tid < 40) cst[tid] = *reinterpret_cast<const v4f*>(p.dw_b + (tid - 36) * 4);
+    else if (tid < 48) cst[tid] = 4 * (tid - 40) < p.Cout ? *reinterpret_cast<const v4f*>(p.bias + 4 * (tid - 40)) : v4f{0.f, 0.f, 0.f, 0.f};
+    const int g = lane >> 4, lp = lane & 15;                               // stem: K block / pixel of the group
+    const v4u* wfrag = reinterpret_cast<const v4u*>(p.stem_wfrag);
+    const v4u wq_hi = wfrag[lane], wq_mid = wfrag[64 + lane], wq_lo = wfrag[128 + lane];
+    const v4f sbias = *reinterpret_cast<const v4f*>(p.stem_bf + 4 * g);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // (an empty asm that READS them: the compiler places its own wait for these loads here, in the prologue — it cannot see the explicit
+    //  s_waitcnt below and would otherwise wait at their first use, inside the tile loop, draining the window prefetch with them)
+    asm volatile("" ::"v"(wq_hi), "v"(wq_mid), "v"(wq_lo), "v"(sbias));
+#endif
+    const bf16x8 w_hi = __builtin_bit_cast(bf16x8, wq_hi), w_mid = __builtin_bit_cast(bf16x8, wq_mid), w_lo = __builtin_bit_cast(bf16x8, wq_lo);
+    const int fr = lane & 31, fh2 = lane >> 5, fsw = (fr >> 1) & 7;
+
+    // ---- everything about a lane's three stem groups that does not depend on the tile: halo pixel (hy, hx), its slot in the staged
+    // image (row rr, byte cb relative to the tile's window origin) and in the halo image
+    constexpr int NG = ((DP_HALO + 15) / 16 + 3) / 4;                       // groups per wave (3)
+    int g_hy[NG], g_hx[NG], g_rq[NG], g_cb[NG], g_hp[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int hp = (wid + 4 * i) * 16 + lp;
+        g_hp[i] = hp < DP_HALO ? hp : -1;
+        g_hy[i] = hp / DP_HW; g_hx[i] = hp - g_hy[i] * DP_HW;
+        const int rr = g_hy[i] * S + (g < 3 ? g : 0);                      // g < 3: window row g;  g = 3: rows 0..2, byte 8
+        g_rq[i] = rr;
+        g_cb[i] = g_hx[i] * S * 3 + (g < 3 ? 0 : 8);
+    }
+    // a halo pixel's window lies inside the frame (and the pixel inside the map) iff  AY0 <= ay <= AY1  and  AX0 <= ax <= AX1
+    const int AY0 = 1, AY1 = min(p.H - 1, (p.u8_srcH - 2) / S), AX0 = (2 + S - 1) / S, AX1 = min(p.W - 1, (p.u8_srcW - 3) / S);
+
+    // ---- tiles of this workgroup: XCD x owns a contiguous run, its workgroups walk it side by side (t, t + wgs, ...); the tile
+    // coordinates move by the same three steps every time: no division in the loop
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, wgs = gridDim.x >> 3;      // (gridDim.x is a multiple of 8)
+    const int q8 = tiles_total >> 3, r8 = tiles_total & 7;
+    const int run0 = xcd * q8 + min(xcd, r8), run1 = run0 + q8 + (xcd < r8 ? 1 : 0);
+    const int d_tx = wgs % tiles_x, d_ty = (wgs / tiles_x) % tiles_y, d_n = wgs / (tiles_x * tiles_y);
+    int t = run0 + wg;
+    int n = t / (tiles_x * tiles_y), tyi = (t / tiles_x) % tiles_y, txi = t % tiles_x;      // the tile being PREFETCHED
+    auto advance = [&]() {
+        txi += d_tx; if (txi >= tiles_x) { txi -= tiles_x; ++tyi; }
+        tyi += d_ty; if (tyi >= tiles_y) { tyi -= tiles_y; ++n; }
+        n += d_n;
+    };
+
+    unsigned pf[FR_SLOTS];
+    const int pr = tid / FR_PITCH, pd4 = (tid % FR_PITCH) * 4;             // this thread's slots: rows pr + 8k, dword pd
+    auto prefetch = [&]() __attribute__((always_inline)) {                // the u8 window of tile (n, tyi, txi) -> registers (issued, not waited for)
+        const uint8_t* frame = p.u8_src + (size_t)n * p.u8_img_stride;
+        const int sy0 = (tyi * DP_TH - 1) * S - 1, sx3 = ((txi * DP_TW - 1) * S - 1) * 3;
+        const unsigned base_lo = (unsigned)(unsigned long long)frame + (unsigned)(sy0 * step + sx3);     // low bits of the window origin's address
+#pragma unroll
+        for (int k = 0; k < FR_SLOTS; ++k) {
+            const int r = pr + (256 / FR_PITCH) * k;
+            const unsigned shr = (STEP4 ? base_lo : base_lo + (unsigned)(r * step)) & 3u;
+            const int rel = sx3 - (int)shr + pd4;                            // byte position in the frame row
+            // dwords that are not entirely inside the frame's row read as 0: only border pixels would look at them, and those take
+            // the per-byte path
+            const bool ok = r < nrows && (unsigned)(sy0 + r) < (unsigned)p.u8_srcH && rel >= 0 && rel + 4 <= row_bytes;
+            pf[k] = ok ? *(const dwpw_gmem_u32*)(frame + (unsigned)((sy0 + r) * step + rel)) : 0u;
+        }
+    };
+
+    // the prologue's loads and the weight DMA have landed — the only full memory wait of the kernel: the barriers of the tile loop
+    // order LDS traffic only (front_barrier), so a tile's prefetch stays in flight across them
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    front_barrier();
+    if (t < run1) prefetch();
+    int buf = 0;
+    for (; t < run1; t += wgs, buf ^= 1) {
+        const int cn = n, cty0 = tyi * DP_TH, ctx0 = txi * DP_TW;          // this tile (n / tyi / txi move on to the prefetched one)
+        const uint8_t* frame = p.u8_src + (size_t)cn * p.u8_img_stride;
+        const int sy0 = (cty0 - 1) * S - 1, sx0 = (ctx0 - 1) * S - 1;
+        const unsigned base_lo = (unsigned)(unsigned long long)frame + (unsigned)(sy0 * step + sx0 * 3);
+        // 1. window: registers -> LDS (waits for the loads issued a whole tile ago), then the next tile's loads
+#pragma unroll
+        for (int k = 0; k < FR_SLOTS; ++k)
+            if (tid + 256 * k < FR_ROWS * FR_PITCH) stage[buf][tid + 256 * k] = pf[k];
+        advance();
+        if (t + wgs < run1) prefetch();
+        front_barrier();
+        // 2. stem.  Pass FAST: every pixel whose 3x9-byte window lies inside the frame, from the staged image — no global access, so no
+        // wait on the prefetch.  Pass BORDER (only tiles that touch the frame's border, a wave-uniform test): the remaining pixels, byte by
+        // byte from global memory (outside the net input = conv zero padding: 127.5 cancels against the folded bias; inside it but outside
+        // the pasted image = letterbox canvas, u8 0).  Kept apart because a global load anywhere in the common loop makes the compiler
+        // drain vmcnt at its join — i.e. wait for the NEXT tile's window in every group.
+        const unsigned* st = stage[buf];
+        // (the whole halo in the map and every window in the frame: AY1 <= H - 1, AX1 <= W - 1)
+        const bool tile_inside = cty0 - 1 >= AY0 && cty0 + DP_TH <= AY1 && ctx0 - 1 >= AX0 && ctx0 + DP_TW <= AX1;
+        auto stem_finish = [&](const float (&f)[8], bool inmap, bool store, int hp) __attribute__((always_inline)) {
+            v4u bq;                                                         // fp32 -> bf16 by truncation: exact for 0..255 and 127.5
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                bq[i] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, f[2 * i + 1]), __builtin_bit_cast(unsigned, f[2 * i]), 0x07060302u);
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bq);
+            v4f a4 = sbias;
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_lo, bfrag, a4, 0, 0, 0);
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_mid, bfrag, a4, 0, 0, 0);
+            a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w_hi, bfrag, a4, 0, 0, 0);
+            if (p.stem_act == (int)Act::RELU) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a4[c] = a4[c] > 0.f ? a4[c] : 0.f;
+            }
+            if (!inmap) a4 = v4f{0.f, 0.f, 0.f, 0.f};                       // outside the map: the depthwise zero padding
+            if (store) halo[hp * 4 + g] = a4;
+        };
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {                                      // (wave-uniform trip count: the MFMAs run with all lanes)
+            if ((wid + 4 * i) * 16 >= DP_HALO) break;
+            const int hp = g_hp[i];
+            bool inmap = hp >= 0, fast = inmap;
+            if (!tile_inside) {
+                const int ay = cty0 + g_hy[i] - 1, ax = ctx0 + g_hx[i] - 1;
+                inmap = inmap && (unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W;
+                fast = inmap && ay >= AY0 && ay <= AY1 && ax >= AX0 && ax <= AX1;
+            }
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.f;
+            if (fast) {
+                if (g < 3) {                                                // 8 bytes at an unaligned position: 3 aligned dwords
+                    const unsigned pos = ((STEP4 ? base_lo : base_lo + (unsigned)(g_rq[i] * step)) & 3u) + (unsigned)g_cb[i];
+                    const unsigned* q = st + g_rq[i] * FR_PITCH + (pos >> 2);
+                    const unsigned sh = pos & 3u;
+                    const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
+                    const unsigned n0 = __builtin_amdgcn_alignbyte(d1, d0, sh), n1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                    f[0] = (float)(n0 & 255u); f[1] = (float)((n0 >> 8) & 255u); f[2] = (float)((n0 >> 16) & 255u); f[3] = (float)(n0 >> 24);
+                    f[4] = (float)(n1 & 255u); f[5] = (float)((n1 >> 8) & 255u); f[6] = (float)((n1 >> 16) & 255u); f[7] = (float)(n1 >> 24);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const unsigned pos = ((STEP4 ? base_lo : base_lo + (unsigned)((g_rq[i] + r) * step)) & 3u) + (unsigned)g_cb[i];
+                        f[r] = (float)((st[(g_rq[i] + r) * FR_PITCH + (pos >> 2)] >> (8u * (pos & 3u))) & 255u);
+                    }
+                }
+            }
+            stem_finish(f, inmap, hp >= 0, hp);
+        }
+        if (!tile_inside) {
+            // BORDER pass: the pixels the FAST pass could not do (it stored zeros or garbage-free zeros for them), same lanes, same wave
+#pragma unroll 1
+            for (int i = 0; i < NG; ++i) {
+                if ((wid + 4 * i) * 16 >= DP_HALO) break;
+                const int hp = g_hp[i];
+                const int ay = cty0 + g_hy[i] - 1, ax = ctx0 + g_hx[i] - 1;
+                const bool inmap = hp >= 0 && (unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W;
+                const bool slow = inmap && !(ay >= AY0 && ay <= AY1 && ax >= AX0 && ax <= AX1);
+                const int iy0 = ay * S - 1, ix0 = ax * S - 1;
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = 0.f;
+                if (slow) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = g < 3 ? g : j, rb = g < 3 ? j : 8;     // window row, byte within the row (pixel rb / 3, channel rb % 3)
+                        if (g == 3 && j >= 3) continue;
+                        const int iy = iy0 + r, ix = ix0 + rb / 3;
+                        float b = 127.5f;
+                        if ((unsigned)iy < (unsigned)p.u8_inH && (unsigned)ix < (unsigned)p.u8_inW) {
+                            b = 0.f;
+                            if (iy < p.u8_srcH && ix < p.u8_srcW) b = (float)frame[(size_t)iy * step + (size_t)ix * 3 + rb % 3];
+                        }
+                        f[j] = b;
+                    }
+                }
+                stem_finish(f, inmap, slow, hp);
+            }
+        }
+        front_barrier();
+        // 3. depthwise 3x3 (+bias +activation) -> A tile
+        {
+            const int py = dp / DP_TW, pxx = dp - py * DP_TW;               // pixels dp and dp + 64 = four rows further down
+            v4f a0 = cst[36 + dq], a1 = a0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const v4f w = cst[(ky * 3 + kx) * 4 + dq];
+                    a0 += halo[((py + ky) * DP_HW + pxx + kx) * 4 + dq] * w;
+                    a1 += halo[((py + 4 + ky) * DP_HW + pxx + kx) * 4 + dq] * w;
+                }
+            if (p.dw_act == (int)Act::RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a0[e] = a0[e] > 0.f ? a0[e] : 0.f; a1[e] = a1[e] > 0.f ? a1[e] : 0.f; }
+            }
+            At[dp * 8 + (dq ^ ((dp >> 1) & 7))] = a0;
+            At[(dp + 64) * 8 + (dq ^ (((dp + 64) >> 1) & 7))] = a1;
+        }
+        front_barrier();
+        // 4. pointwise: wave = 32 pixels x 32 output channels, K = 16
+        v16f acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const v4f* X = At + (wid * 32 + fr) * 8;
+        const v4f* Wp = Wt + fr * 8;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int col = (2 * s2 + fh2) ^ fsw;
+            const v4f x = X[col], w = Wp[col];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
+        }
+        const int r = wid * 32 + fr;
+        const int oy = cty0 + r / DP_TW, ox = ctx0 + r % DP_TW;
+        if (oy < p.Ho && ox < p.Wo) {
+            float* __restrict__ orow = p.out1 + (((size_t)cn * p.Ho + oy) * p.Wo + ox) * p.Cout;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int co = 4 * fh2 + 8 * q;
+                if (co >= p.Cout) continue;
+                const v4f pb = cst[40 + fh2 + 2 * q];
+                v4f v;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float u = acc[4 * q + c] + pb[c];
+                    if (p.act == (int)Act::RELU) u = u > 0.f ? u : 0.f;
+                    v[c] = u;
+                }
+                *reinterpret_cast<v4f*>(orow + co) = v;
+            }
+        }
+    }
+}
+
+bool front_fused_ok(int Cin, int Cout, int dw_stride) { return Cin == 16 && dw_stride == 1 && Cout <= 32 && Cout % 4 == 0; }
+
+static void launch_front(const ConvArgs& a, hipStream_t s) {
+    if (!front_fused_ok(a.Cin, a.Cout, a.dw_stride) || a.Kpad != 32 || (a.u8_stride != 1 && a.u8_stride != 2) || !a.stem_wfrag)
+        throw std::runtime_error("dwpw: the fused stem needs 16 channels, stride 1 and Cout <= 32 (multiple of 4)");
+    if ((long)a.u8_srcH * a.u8_step >= (1L << 31)) throw std::runtime_error("dwpw: frame too large for 32-bit byte offsets");
+    const int tiles_x = (a.Wo + DP_TW - 1) / DP_TW, tiles_y = (a.Ho + DP_TH - 1) / DP_TH;
+    const int tiles_total = a.B * tiles_y * tiles_x;
+    const int cus = a.cus > 0 ? a.cus : conv_num_cus();
+    const int grid = std::min((tiles_total + 7) / 8 * 8, cus * 4);        // persistent: 4 workgroups per CU, a multiple of 8 (XCDs)
+    const dim3 g3((unsigned)std::max(8, grid / 8 * 8));
+    if (a.u8_step % 4 == 0) hipLaunchKernelGGL(front_kernel<true>, g3, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_total);
+    else hipLaunchKernelGGL(front_kernel<false>, g3, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_total);
+}
+
 void launch_dwpw(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
     a.zeros = conv_zero_line();
     if ((long)a.B * a.Ho * a.Wo <= 0) return;
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
-    if (a.Cout <= 32) launch_dwpw_cfg<32, 4, 1>(a, s);
+    if (a.u8_src) launch_front(a, s);
+    else if (a.Cout <= 32) launch_dwpw_cfg<32, 4, 1>(a, s);
     else if (a.Cout <= 64) launch_dwpw_cfg<64, 2, 2>(a, s);
     else if (a.Cout <= 96) launch_dwpw_cfg<96, 4, 1>(a, s);
     else launch_dwpw_cfg<128, 2, 2>(a, s);

@@ -265,6 +265,13 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
             }
             dev_[0].wf = push(wf.data(), wf.size());
             dev_[0].bf = push(bf.data(), bf.size());
+            if (op.Cout == 16) {                                   // the fused front's matrix-core stem: the same weights as bf16 fragments
+                std::vector<unsigned> fr(3 * 64 * 4, 0u);
+                stem_pack_wfrag(wf.data(), fr.data());
+                std::vector<float> asf(fr.size());
+                memcpy(asf.data(), fr.data(), fr.size() * 4);
+                dev_[0].wfr = push(asf.data(), asf.size());
+            }
         }
     }
     if (stem_ok_ && plan_.ops.size() > 1) {   // can the stem also be pulled into the depthwise -> pointwise block that consumes it?
@@ -274,7 +281,7 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
         for (const auto& o : plan_.ops) for (int x : {o.in, o.in2, o.res}) if (x == st.out) ++uses;
         for (const auto& o : plan_.outputs) if (o.tensor == st.out) ++uses;
         front_ok_ = st.Cout == 16 && st.out >= 0 && st.out2 < 0 && (st.act == Act::NONE || st.act == Act::RELU) && nx.kind == OpKind::DWPW &&
-                    nx.in == st.out && uses == 1 && nx.dw_stride == 1 && nx.Cin == 16 && nx.Cout <= 64;
+                    nx.in == st.out && uses == 1 && front_fused_ok(nx.Cin, nx.Cout, nx.dw_stride);
     }
     params_.ensure(std::max<size_t>(host.size(), 64) * sizeof(float));
     FH_HIP(hipMemcpy(params_.p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -317,6 +324,8 @@ void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int st
         a.ks = 1; a.stride = 1; a.pad = 0; a.Kpad = d.Kpad; a.act = (int)op.act;
         a.u8_src = src; a.u8_img_stride = img_stride; a.u8_step = step; a.u8_srcH = srcH; a.u8_srcW = srcW; a.u8_inH = plan_.inH; a.u8_inW = plan_.inW;
         a.u8_stride = st.stride; a.stem_act = (int)st.act; a.stem_wf = P + d0.wf; a.stem_bf = P + d0.bf;
+        a.stem_wfrag = reinterpret_cast<const unsigned*>(P + d0.wfr);
+        a.cus = cus;
         a.t_flops = 2.0 * (st.macs + op.macs) * batch;
         a.t_bytes = ((double)srcH * srcW * 3 + (double)op.Ho * op.Wo * op.Cout * 4) * batch;        // u8 frame in, pointwise map out
         launch_dwpw(a, s);

@@ -60,6 +60,7 @@ class Net {
         size_t wt = 0, bias = 0, slope = 0, s2 = 0, t2 = 0;   // float offsets into params_
         bool has_slope = false, has_aff = false;
         size_t w27 = 0;                                       // stem layout [27][Cout] (op 0 only)
+        size_t wfr = 0;                                       // ... and wf as bf16 MFMA fragments (stem_pack_wfrag), 16-channel stems
         size_t wf = 0, bf = 0;                                // ... and with the u8 normalisation folded in (byte order, w / 128; adjusted bias)
         size_t dww = 0, dwb = 0;                              // fused depthwise front end (DWPW)
         size_t w36 = 0;                                       // Winograd F(4,3) weights U[36][rows][Cin]

@@ -73,6 +73,7 @@ struct ConvArgs {
     int u8_step, u8_srcH, u8_srcW, u8_inH, u8_inW, u8_stride, stem_act;
     const float* stem_wf;
     const float* stem_bf;
+    const unsigned* stem_wfrag;   // launch_dwpw's fused stem: stem_wf as bf16 MFMA fragments (stem_pack_wfrag)
     int n_outs;             // > 0: merged sibling convs — channels [oc0[g], oc0[g+1]) go to outs[g] with act oact[g]
     float* outs[3];
     int oc0[4];
@@ -103,6 +104,8 @@ size_t conv_halo_wfrag_floats(int Cin, int Cout);
 void conv_halo_pack_weights(const float* w_ohwi, int Cout, int Cin, float* dst);
 void launch_conv_halo(const ConvArgs& a, const float* wfrag, hipStream_t s);
 // depthwise 3x3 stride 1 (+bias +act) fused with the 1x1 conv that consumes it (dwpw_mfma.hip)
+void stem_pack_wfrag(const float* wf, unsigned* out);   // wf [27][16] (folded stem weights) -> [3][64][4] dwords, see dwpw_mfma.hip
+bool front_fused_ok(int Cin, int Cout, int dw_stride);   // the opening block (u8 stem + depthwise + pointwise) has a one-kernel form
 void launch_dwpw(const ConvArgs& a, hipStream_t s);
 // Winograd F(4x4,3x3) form of a 3x3 stride-1 pad-1 convolution (winograd.hip): a = the convolution's arguments,
 // wt36 = U[36][conv_wt_rows(Cout)][Cin], V / M = workspaces of 36 * tiles * max(Cin, Cout) floats each

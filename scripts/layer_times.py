@@ -22,6 +22,8 @@ else:
     path = models.cached("det_500m_seed100.onnx", models.make_det_500m)
     net = fa.FaceDetector(); assert net.loadModel(path)
     L.fh_det_set_conv_cfg(net.handle, cfg, sk)
+    front = os.environ.get("FACEHIP_NO_FRONT") != "1"
+    L.fh_det_set_fused_front(net.handle, 1 if front else 0)
     data = torch.from_numpy(rng.integers(0, 256, (B, 640, 640, 3), dtype=np.uint8)).cuda()
     run = lambda: L.fh_det_run_network_dev(net.handle, data.data_ptr(), B, 640, 640, 1920, 640 * 1920, 0)
     desc = fa.plan_describe(path, 640, 640)
@@ -30,6 +32,8 @@ ops = [l for l in desc.splitlines()[1:] if l and l[0].isdigit()]
 folded = {int(m.group(1)) for l in ops for m in [re.search(r"sc<-op(\d+)", l)] if m}      # shortcuts that run inside their consumer
 if os.environ.get("FACEHIP_NO_SC_FOLD") != "1":
     ops = [l for l in ops if int(l.split()[0]) not in folded]
+if which == "det" and front:                                     # ops 0 + 1 run as one kernel (stem inside the first depthwise block)
+    ops = ["0+1 fused front: " + ops[1].split(" ", 1)[1]] + ops[2:]
 for _ in range(3): run()
 torch.cuda.synchronize()
 L.fh_timing_enable(1)
