@@ -82,9 +82,14 @@ struct Tile {
 
 // ---- epilogue shared by the main kernel and the fix-up kernel -------------------------------
 // C/D map of the 32x32 MFMA: column (= pixel here) = lane & 31, row (= channel) = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+// ep (optional): the tile's per-channel vectors in LDS, float [12][BN]: rows 0..8 = bias (one per border class when bias_cls, else row 0),
+// 9 = PReLU slope, 10 / 11 = s2 / t2 of the second output; channels >= Cout hold 0.  With it the epilogue issues NO global load between
+// its stores: on this ISA loads and stores share one in-order counter (vmcnt), so a load issued after a store can only be waited for
+// together with that store's acknowledgement — bias / slope loads interleaved with the stores turned the epilogue into a chain of
+// store round trips (16 per 256x64 tile, a third of the tile's time).  The residual reads are issued up front for the same reason.
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0,
-                                              int wm, int wn, int lane, int only_i = -1, int only_j = -1) {
+                                              int wm, int wn, int lane, int only_i = -1, int only_j = -1, const float* ep = nullptr) {
     using TL = Tile<BM, BN, WM, WN>;
     const int fr = lane & 31, fh2 = lane >> 5;
     const int HoWo = p.Ho * p.Wo;
@@ -110,6 +115,57 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
                     const int cg = p.oc0[g + 1] - p.oc0[g];
                     const float v = apply_act(acc[i][j][e] + p.bias[co], p.oact[g], 0.f);
                     p.outs[g][(size_t)m * cg + (co - p.oc0[g])] = v;
+                }
+            }
+        }
+        return;
+    }
+    if (ep && vec) {
+        // per 32-pixel row block: its TN*4 residual float4s first, then per accumulator quad vectors from LDS, arithmetic, stores
+        // (all TM row blocks' residuals up front would not fit the register file of the large tiles)
+#pragma unroll
+        for (int i = 0; i < TL::TM; ++i) {
+            const int m = m0 + (wm * TL::TM + i) * 32 + fr;
+            if (m >= M) continue;
+            const size_t row = (size_t)m * p.Cout;
+            int cls = 0;
+            size_t rrow = row;
+            if (p.bias_cls || p.res_mode == (int)ResMode::UP2X) {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                // BatchNorm shift folded in: taps that fall on the zero padding contribute none of it
+                if (p.bias_cls) cls = 3 * (oy == 0 ? 0 : oy == p.Ho - 1 ? 2 : 1) + (ox == 0 ? 0 : ox == p.Wo - 1 ? 2 : 1);
+                if (p.res_mode == (int)ResMode::UP2X) rrow = ((size_t)(n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout;
+            }
+            v4f r4[TL::TN][4];
+            if (p.res_mode != (int)ResMode::NONE) {
+#pragma unroll
+                for (int j = 0; j < TL::TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = n0 + (wn * TL::TN + j) * 32 + 4 * fh2 + 8 * g;
+                        r4[j][g] = co < p.Cout ? *reinterpret_cast<const v4f*>(res + rrow + co) : v4f{0.f, 0.f, 0.f, 0.f};
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < TL::TN; ++j) {
+                const int cl = (wn * TL::TN + j) * 32 + 4 * fh2;           // channel within the tile
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = n0 + cl + 8 * g;
+                    if (co >= p.Cout) continue;
+                    const v4f b4 = *reinterpret_cast<const v4f*>(ep + cls * BN + cl + 8 * g);
+                    v4f sl = {0.f, 0.f, 0.f, 0.f};
+                    if (p.act == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(ep + 9 * BN + cl + 8 * g);
+                    v4f v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = apply_act(acc[i][j][4 * g + c] + b4[c], p.act, sl[c]);
+                    if (p.res_mode != (int)ResMode::NONE) v += r4[j][g];
+                    if (out1) *reinterpret_cast<v4f*>(out1 + row + co) = v;
+                    if (out2) {
+                        const v4f s2 = *reinterpret_cast<const v4f*>(ep + 10 * BN + cl + 8 * g), t2 = *reinterpret_cast<const v4f*>(ep + 11 * BN + cl + 8 * g);
+                        *reinterpret_cast<v4f*>(out2 + row + co) = v * s2 + t2;
+                    }
                 }
             }
         }
@@ -367,6 +423,23 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+        // the epilogue's per-channel vectors (see conv_epilogue: ep), fetched now into a few registers and parked in LDS once the K loop
+        // has released it — no global read is left for the epilogue to wait on
+        constexpr int EPN = (12 * BN + WM * WN * 64 - 1) / (WM * WN * 64);
+        const bool use_ep = role != HELPER && p.n_outs == 0 && (p.Cout & 3) == 0;
+        float epv[EPN];
+#pragma unroll
+        for (int k = 0; k < EPN; ++k) {
+            const int e = tid + k * (WM * WN * 64), a = e / BN, c = e - a * BN, co = n0 + c;
+            float v = 0.f;
+            if (use_ep && a < 12 && co < p.Cout) {
+                if (a < 9) { if (p.bias && (a == 0 || p.bias_cls)) v = p.bias[a * p.Cout + co]; }
+                else if (a == 9) { if (p.act == (int)Act::PRELU) v = p.slope[co]; }
+                else if (p.out2) v = a == 10 ? p.s2[co] : p.t2[co];
+            }
+            epv[k] = v;
+        }
+
         auto compute = [&](int buf) {
             const v4f* X = lds[buf] + (wm * TM * 32 + fr) * 8;
             const v4f* Wt = lds[buf] + BM * 8 + (wn * TN * 32 + fr) * 8;
@@ -459,7 +532,16 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                         }
             }
         }
-        conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane);
+        float* const ep = reinterpret_cast<float*>(&lds[0][0]);            // (every wave is past the K loop's last barrier: LDS is free)
+        if (use_ep) {
+#pragma unroll
+            for (int k = 0; k < EPN; ++k) {
+                const int e = tid + k * (WM * WN * 64);
+                if (e < 12 * BN) ep[e] = epv[k];
+            }
+            __syncthreads();
+        }
+        conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane, -1, -1, use_ep ? ep : nullptr);
     } while (role == HELPER && hu < hu_end);
 }
 

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2)
     constexpr int SR = BM / PPP;                                           // DIRECT: output rows per thread strip
     constexpr int NR = (SR - 1) * DS + 3;                                  //         input rows a strip touches
     __shared__ v4f lds[HALO_SLOTS + BM * 8 + BN * 8];
+    __shared__ float bias_s[BN];                                           // pointwise bias of this tile's columns (see the epilogue)
     v4f* const halo = lds;
     v4f* const At = lds + HALO_SLOTS;
     v4f* const Wt = At + BM * 8;
@@ -117,6 +118,9 @@ __global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // fetched now, parked in LDS under the first chunk's barrier: the epilogue then issues no global load between its stores (loads and
+    // stores share the in-order vmcnt: a bias load after a store waits for that store's acknowledgement — 12 round trips per tile)
+    const float bias_v = (tid < BN && n0 + tid < p.Cout) ? p.bias[n0 + tid] : 0.f;
     for (int kc = 0; kc < chunks; ++kc) {
         const int c0 = kc * 32;
         const bool hvalid = c0 + hq * 4 < C;                               // 16-byte columns past C are never read: no DMA for them
@@ -199,6 +203,7 @@ __global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2)
                 }
             }
         }
+        if (kc == 0 && tid < BN) bias_s[tid] = bias_v;
         __syncthreads();                                                   // A tile complete
         const v4f* X = At + (wm * TM * 32 + fr) * 8;
         const v4f* Wp = Wt + (wn * TN * 32 + fr) * 8;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2)
                 const int co = cb + 8 * g;
                 if (co >= p.Cout) continue;
                 if (vec) {
-                    const v4f bb = *reinterpret_cast<const v4f*>(p.bias + co);
+                    const v4f bb = *reinterpret_cast<const v4f*>(bias_s + (co - n0));
                     v4f v;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
