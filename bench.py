@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
+    ap.add_argument("--cpu-budget-s", type=float, default=25.0, help="wall-clock bound of each CPU baseline leg (the sample stops early)")
     ap.add_argument("--gallery", type=int, default=0, help="config C4/C5: also match every embedding against a gallery of this many "
                     "512-d rows (row-sharded over the ranks; per-rank top-k all-gathered and merged)")
     ap.add_argument("--topk", type=int, default=16)
@@ -155,18 +156,26 @@ def cpu_baseline(det_path, rec_path, frames_np, args, threads=None):
     n = max(1, min(args.cpu_sample_frames, len(frames_np)))
     t0 = time.perf_counter()
     faces = 0
+    done = 0
     for i in range(n):
         if args.workload == "embed":
             orc.embed_aligned(frames_np[i])
             faces += 1
-            continue
-        det = od.detect(frames_np[i], args.score_thr, args.nms_thr)
-        if args.workload == "detect":
-            faces += 1
-            continue
-        for f in det[:args.faces_per_frame]:
-            if orc.extractFeature(frames_np[i], f).size:
+        else:
+            det = od.detect(frames_np[i], args.score_thr, args.nms_thr)
+            if args.workload == "detect":
                 faces += 1
+            else:
+                for f in det[:args.faces_per_frame]:
+                    if orc.extractFeature(frames_np[i], f).size:
+                        faces += 1
+        done = i + 1
+        el = time.perf_counter() - t0
+        if done % 4 == 0 or el > args.cpu_budget_s:
+            print(f"[bench] cpu baseline ({threads} threads): {done}/{n} sample units, {el:.1f} s", file=sys.stderr, flush=True)
+        if el > args.cpu_budget_s:                       # bounded sample: the default run must finish within minutes on any host
+            break
+    n = done
     dt = time.perf_counter() - t0
     unit = "frames/s" if args.workload == "detect" else "faces/s"
     what = {"e2e": f"{n} of the batch's 640x640 frames: detect + decode + NMS + align + embed of the first "
@@ -520,8 +529,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(det_path, rec_path, host, args)                  # the reference's own setting: 4 threads
             ncpu = out["cpu_baseline"]["host_cores_available"]
-            if ncpu > 4:                                                                        # all cores this process may use
-                out["cpu_baseline_all_cores"] = cpu_baseline(det_path, rec_path, host, args, threads=ncpu)
+            if ncpu > 4:                                     # all cores of this process's CPU share (a GPU box gives 16 per GPU;
+                # more OpenMP threads than that only spin against the cgroup quota)
+                out["cpu_baseline_all_cores"] = cpu_baseline(det_path, rec_path, host, args, threads=min(ncpu, 16))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -60,6 +60,11 @@ __global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2)
     __shared__ v4f lds[HALO_SLOTS + BM * 8 + BN * 8];
     __shared__ float bias_s[BN];                                           // pointwise bias of this tile's columns (see the epilogue)
     v4f* const halo = lds;
+    // LDS-halo form: the spare slots behind the 180 halo pixels (the DMA passes cover whole multiples of 256) carry the chunk's 9
+    // depthwise tap vectors + bias, [10][HC] float4: same DMA instructions, no extra LDS, and ten global loads per thread less
+    // (2 560 per workgroup and chunk — more vector-memory instructions than the halo itself)
+    const v4f* const dww_s = halo + DP_HALO * HC;
+    static_assert(DIRECT || DP_HALO * HC + 10 * HC <= HALO_SLOTS, "no room for the depthwise weights behind the halo");
     v4f* const At = lds + HALO_SLOTS;
     v4f* const Wt = At + BM * 8;
 
@@ -97,6 +102,8 @@ __global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2)
         }
     }
     const int hq = tid % HC;                                               // same for every pass (256 % HC == 0)
+    const int wslot_raw = (HP - 1) * 256 + tid - DP_HALO * HC;              // >= 0: slot behind the halo pixels
+    const int wslot = (!DIRECT && wslot_raw >= 0 && wslot_raw < 10 * HC) ? wslot_raw : -1;
     // ---- pointwise weight loader (as conv_mfma.hip: LDS-DMA, swizzle on the source column)
     const int lrow = tid >> 3;
     const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);
@@ -126,11 +133,17 @@ __global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2)
         const bool hvalid = c0 + hq * 4 < C;                               // 16-byte columns past C are never read: no DMA for them
         const int ksteps = min(4, (C - c0 + 7) >> 3);                      // 8-deep MFMA steps that hold real channels
         __syncthreads();                                                   // previous chunk: halo + fragments fully consumed
-        if (!DIRECT && hvalid) {
+        if (!DIRECT) {
 #pragma unroll
             for (int j = 0; j < HP; ++j) {
                 const float* src = h_off[j] >= 0 ? img + h_off[j] + c0 : p.zeros;
-                dwpw_dma16(src, halo + j * 256 + wid * 64);
+                bool go = hvalid;
+                if (j == HP - 1 && wslot >= 0) {                            // this lane's slot of the last pass holds a weight vector
+                    const int k = wslot / HC, ch = c0 + (wslot - k * HC) * 4;
+                    src = ch < C ? (k < 9 ? p.dw_w + (size_t)k * C + ch : p.dw_b + ch) : p.zeros;
+                    go = true;
+                }
+                if (go) dwpw_dma16(src, halo + j * 256 + wid * 64);
             }
         }
 #pragma unroll
@@ -140,11 +153,16 @@ __global__ __launch_bounds__(256, DIRECT ? (HC == 4 ? 3 : BN * DS <= 64 ? 3 : 2)
         const int cw = c0 + dq * 4;
         const bool cvalid = cw < C;
         v4f wk[9], b4;
+        if (DIRECT) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const v4f*>(cvalid ? p.dw_w + (size_t)k * C + cw : p.zeros);
-        b4 = *reinterpret_cast<const v4f*>(cvalid ? p.dw_b + cw : p.zeros);
+            for (int k = 0; k < 9; ++k) wk[k] = *reinterpret_cast<const v4f*>(cvalid ? p.dw_w + (size_t)k * C + cw : p.zeros);
+            b4 = *reinterpret_cast<const v4f*>(cvalid ? p.dw_b + cw : p.zeros);
+        }
         if (!DIRECT) {
             __syncthreads();                                               // halo + weights landed (barrier drains vmcnt)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[k] = dww_s[k * HC + dq];
+            b4 = dww_s[9 * HC + dq];
             if (dq < 2 * ksteps) {
 #pragma unroll
                 for (int i = 0; i < BM / PPP; ++i) {

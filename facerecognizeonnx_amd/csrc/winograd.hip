@@ -160,6 +160,16 @@ __global__ __launch_bounds__(256, 2) void wino_output_kernel(const WinoOutArgs p
             if (oy >= p.H) continue;
             v4f y[4];
             wino_at(t[r], y);
+            // the row's four residual reads BEFORE its stores: loads and stores share the in-order vmcnt, a residual read issued after a
+            // store can only be waited for together with that store's acknowledgement (16 round trips per thread otherwise; all 16 reads
+            // up front would not fit the register file here — the fused kernel does that)
+            v4f rs[4];
+            if (p.res) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    rs[x] = 4 * tx + x < p.W ? *reinterpret_cast<const v4f*>(p.res + (((size_t)b * p.H + oy) * p.W + 4 * tx + x) * C + c4 * 4)
+                                             : v4f{0.f, 0.f, 0.f, 0.f};
+            }
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 const int ox = 4 * tx + x;
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void wino_output_kernel(const WinoOutArgs p
                     v[e] = u;
                 }
                 const size_t o = (((size_t)b * p.H + oy) * p.W + ox) * C + c4 * 4;
-                if (p.res) v += *reinterpret_cast<const v4f*>(p.res + o);
+                if (p.res) v += rs[x];
                 if (p.out1) *reinterpret_cast<v4f*>(p.out1 + o) = v;
                 if (p.out2) *reinterpret_cast<v4f*>(p.out2 + o) = v * s2 + t2;
             }
@@ -229,6 +239,17 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFuseArgs a
             for (int r = 0; r < 4; ++r) t[r][j] = y[r];
         }
         const v4f b4 = p.bias ? *reinterpret_cast<const v4f*>(p.bias + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+        v4f rs[4][4];                                        // residual reads before the first store (see wino_output_kernel)
+        if (p.res) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int oy = 4 * ty + r, ox = 4 * tx + x;
+                    rs[r][x] = (oy < p.H && ox < p.W) ? *reinterpret_cast<const v4f*>(p.res + (((size_t)b * p.H + oy) * p.W + ox) * C + c4 * 4)
+                                                      : v4f{0.f, 0.f, 0.f, 0.f};
+                }
+        }
         v4f sl = {0.f, 0.f, 0.f, 0.f}, s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
         if (p.act == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(p.slope + c4 * 4);
         if (p.s2) { s2 = *reinterpret_cast<const v4f*>(p.s2 + c4 * 4); t2 = *reinterpret_cast<const v4f*>(p.t2 + c4 * 4); }
@@ -252,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFuseArgs a
                     v[e] = u;
                 }
                 const size_t o = (((size_t)b * p.H + oy) * p.W + ox) * C + c4 * 4;
-                if (p.res) v += *reinterpret_cast<const v4f*>(p.res + o);
+                if (p.res) v += rs[r][x];
                 if (p.out1) *reinterpret_cast<v4f*>(p.out1 + o) = v;
                 const v4f vb = v * s2 + t2;
                 if (p.out2) *reinterpret_cast<v4f*>(p.out2 + o) = vb;
