@@ -103,7 +103,11 @@ __global__ __launch_bounds__(256, 2) void wino_input_kernel(const float* __restr
             for (int r = 0; r < 6; ++r) {
                 const int iy = iy0 + r;
                 const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                d[r] = ok ? *reinterpret_cast<const v4f*>(img + ((size_t)iy * W + ix) * C) * as4 + at4 : v4f{0.f, 0.f, 0.f, 0.f};
+                // UNCONDITIONAL load (out-of-image taps read pixel 0 and are zeroed afterwards): a load under a branch is waited for at
+                // the branch's join — 36 serialised memory latencies per thread instead of 36 loads in flight
+                const v4f raw = *reinterpret_cast<const v4f*>(img + (ok ? ((size_t)iy * W + ix) * C : (size_t)0));
+                const float okf = ok ? 1.f : 0.f;                    // (a select on the RESULT would let the compiler sink the load back under a branch)
+                d[r] = raw * (as4 * okf) + at4 * okf;
             }
             v4f tc[6];
             wino_bt(d, tc);
@@ -167,8 +171,7 @@ __global__ __launch_bounds__(256, 2) void wino_output_kernel(const WinoOutArgs p
             if (p.res) {
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
-                    rs[x] = 4 * tx + x < p.W ? *reinterpret_cast<const v4f*>(p.res + (((size_t)b * p.H + oy) * p.W + 4 * tx + x) * C + c4 * 4)
-                                             : v4f{0.f, 0.f, 0.f, 0.f};
+                    rs[x] = *reinterpret_cast<const v4f*>(p.res + (((size_t)b * p.H + oy) * p.W + min(4 * tx + x, p.W - 1)) * C + c4 * 4);   // (clamped: unconditional load)
             }
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
@@ -246,8 +249,7 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFuseArgs a
 #pragma unroll
                 for (int x = 0; x < 4; ++x) {
                     const int oy = 4 * ty + r, ox = 4 * tx + x;
-                    rs[r][x] = (oy < p.H && ox < p.W) ? *reinterpret_cast<const v4f*>(p.res + (((size_t)b * p.H + oy) * p.W + ox) * C + c4 * 4)
-                                                      : v4f{0.f, 0.f, 0.f, 0.f};
+                    rs[r][x] = *reinterpret_cast<const v4f*>(p.res + (((size_t)b * p.H + min(oy, p.H - 1)) * p.W + min(ox, p.W - 1)) * C + c4 * 4);   // (clamped: unconditional)
                 }
         }
         v4f sl = {0.f, 0.f, 0.f, 0.f}, s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
