@@ -1,4 +1,4 @@
-"""bench.py's output contract, checked on the committed line of the last measured run (profiles/r01_bench_line.json)
+"""bench.py's output contract, checked on the committed line of the last measured run (profiles/r02_bench_line.json)
 and on the argument parser (no GPU needed)."""
 import json
 import os
@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r01_bench_line.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02_bench_line.json")) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert d["metric"].replace("x", "×") == base["metric"] or d["metric"] == base["metric"].replace("×", "x")
@@ -22,8 +22,10 @@ def test_committed_bench_line_has_the_contract_fields():
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and r["peak"] == 157.3
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
     assert r["traffic"] is None or r["traffic"] > 0
-    c = d["cpu_baseline"]
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    for key in ("cpu_baseline", "cpu_baseline_all_cores"):
+        c = d[key]
+        assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["cpu"]
+    assert d["cpu_baseline"]["cores"] == 4 and d["cpu_baseline_all_cores"]["cores"] <= 16
     # value = faces the step produced / step time
     faces = d["config"]["faces_per_step_rank0"] * d["n_gpus"]
     assert abs(d["value"] - faces / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
