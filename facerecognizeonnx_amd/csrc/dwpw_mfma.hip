@@ -332,28 +332,29 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // Folded stem weights wf [27][16] (tap-major: (ky*9 + kx*3 + byte) x channel) as the A fragments of v_mfma_f32_16x16x32_bf16: three
 // bf16 terms (hi, mid, lo — their sum is the fp32 weight exactly), lane l = channel l & 15, K block l >> 4; K index 8g + j = byte j of
-// window row g (g < 3), 24 + r = byte 8 of row r, 27..31 = 0.  out: [3][64][4] dwords.
-void stem_pack_wfrag(const float* wf, unsigned* out) {
+// window row g (g < 3), 24 + r = byte 8 of row r, 27..31 = 0.  One [3][64][4]-dword block per 16 output channels.
+void stem_pack_wfrag(const float* wf, int Cout, unsigned* out) {             // Cout % 16 == 0; out: [Cout / 16][3][64][4] dwords
     auto bf = [](float x) {                                                // round to nearest even, as bits
         unsigned u; memcpy(&u, &x, 4);
         u += 0x7fffu + ((u >> 16) & 1u);
         return u >> 16;
     };
     auto fl = [](unsigned b) { unsigned u = b << 16; float x; memcpy(&x, &u, 4); return x; };
-    for (int l = 0; l < 64; ++l)
-        for (int j = 0; j < 8; ++j) {
-            const int co = l & 15, k = 8 * (l >> 4) + j;
-            float w = 0.f;
-            if (k < 24) w = wf[((k >> 3) * 9 + (k & 7)) * 16 + co];
-            else if (k < 27) w = wf[((k - 24) * 9 + 8) * 16 + co];
-            const unsigned hi = bf(w); const float r1 = w - fl(hi);
-            const unsigned mid = bf(r1); const float r2 = r1 - fl(mid);
-            const unsigned t[3] = {hi, mid, bf(r2)};
-            for (int q = 0; q < 3; ++q) {
-                unsigned& d = out[(q * 64 + l) * 4 + (j >> 1)];
-                d = (j & 1) ? (d | (t[q] << 16)) : t[q];
+    for (int cb = 0; cb < Cout / 16; ++cb)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int co = cb * 16 + (l & 15), k = 8 * (l >> 4) + j;
+                float w = 0.f;
+                if (k < 24) w = wf[((k >> 3) * 9 + (k & 7)) * Cout + co];
+                else if (k < 27) w = wf[((k - 24) * 9 + 8) * Cout + co];
+                const unsigned hi = bf(w); const float r1 = w - fl(hi);
+                const unsigned mid = bf(r1); const float r2 = r1 - fl(mid);
+                const unsigned t[3] = {hi, mid, bf(r2)};
+                for (int q = 0; q < 3; ++q) {
+                    unsigned& d = out[((cb * 3 + q) * 64 + l) * 4 + (j >> 1)];
+                    d = (j & 1) ? (d | (t[q] << 16)) : t[q];
+                }
             }
-        }
 }
 
 constexpr int FR_PITCH = 32;                                               // dwords per staged u8 row: (17*2+3)*3 + 3 bytes <= 128

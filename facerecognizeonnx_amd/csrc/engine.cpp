@@ -265,9 +265,9 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
             }
             dev_[0].wf = push(wf.data(), wf.size());
             dev_[0].bf = push(bf.data(), bf.size());
-            if (op.Cout == 16) {                                   // the fused front's matrix-core stem: the same weights as bf16 fragments
-                std::vector<unsigned> fr(3 * 64 * 4, 0u);
-                stem_pack_wfrag(wf.data(), fr.data());
+            if (op.Cout % 16 == 0) {                               // matrix-core stems (fused front, stem_mfma_kernel): the same weights as bf16 fragments
+                std::vector<unsigned> fr((size_t)(op.Cout / 16) * 3 * 64 * 4, 0u);
+                stem_pack_wfrag(wf.data(), op.Cout, fr.data());
                 std::vector<float> asf(fr.size());
                 memcpy(asf.data(), fr.data(), fr.size() * 4);
                 dev_[0].wfr = push(asf.data(), asf.size());
@@ -341,7 +341,7 @@ void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int st
         launch_stem_conv_u8(src, img_stride, srcH, srcW, step, batch, plan_.inH, plan_.inW, op.stride, op.Cout, P + d.w27, P + d.bias, P + d.wf,
                             P + d.bf, d.has_slope ? P + d.slope : nullptr, (int)op.act, op.out >= 0 ? tensor_ptr(op.out) : nullptr,
                             op.out2 >= 0 && !d.bn_fold_dst ? tensor_ptr(op.out2) : nullptr, d.has_aff ? P + d.s2 : nullptr,
-                            d.has_aff ? P + d.t2 : nullptr, s);
+                            d.has_aff ? P + d.t2 : nullptr, s, d.wfr ? reinterpret_cast<const unsigned*>(P + d.wfr) : nullptr);
         timer.end(s, 5, 2.0 * op.macs * batch, op.bytes * batch);
         run(batch, s, 1);
         return;

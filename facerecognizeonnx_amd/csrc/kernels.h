@@ -104,7 +104,7 @@ size_t conv_halo_wfrag_floats(int Cin, int Cout);
 void conv_halo_pack_weights(const float* w_ohwi, int Cout, int Cin, float* dst);
 void launch_conv_halo(const ConvArgs& a, const float* wfrag, hipStream_t s);
 // depthwise 3x3 stride 1 (+bias +act) fused with the 1x1 conv that consumes it (dwpw_mfma.hip)
-void stem_pack_wfrag(const float* wf, unsigned* out);   // wf [27][16] (folded stem weights) -> [3][64][4] dwords, see dwpw_mfma.hip
+void stem_pack_wfrag(const float* wf, int Cout, unsigned* out);   // wf [27][Cout] (folded stem weights) -> [Cout/16][3][64][4] dwords, see dwpw_mfma.hip
 bool front_fused_ok(int Cin, int Cout, int dw_stride);   // the opening block (u8 stem + depthwise + pointwise) has a one-kernel form
 void launch_dwpw(const ConvArgs& a, hipStream_t s);
 // Winograd F(4x4,3x3) form of a 3x3 stride-1 pad-1 convolution (winograd.hip): a = the convolution's arguments,
@@ -165,9 +165,10 @@ void launch_rec_preprocess(const uint8_t* crops, int n, int H, int W, float* out
 // w27 = [27][Cout] with k = (ky*3+kx)*3 + ci (ci in RGB order); act as fh::Act.
 // wf / biasf (optional): the same filter with the normalisation folded in, for the thread-per-pixel kernel: wf[(tap*3 + j)][Cout] =
 // w27[tap*3 + (2-j)] / 128 (j = byte of the BGR pixel), biasf = bias - 127.5/128 * sum_k w27[k].
+// wfrag (optional, Cout % 16 == 0, Cout <= 64): the folded weights as bf16 MFMA fragments (stem_pack_wfrag) -> matrix-core stem kernel
 void launch_stem_conv_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int B, int inH, int inW, int stride,
                          int Cout, const float* w27, const float* bias, const float* wf, const float* biasf, const float* slope, int act,
-                         float* out1, float* out2, const float* s2, const float* t2, hipStream_t s);
+                         float* out1, float* out2, const float* s2, const float* t2, hipStream_t s, const unsigned* wfrag = nullptr);
 
 struct DecodeArgs {
     const float* score[3];  // per stride [B, gh*gw*2]

@@ -512,9 +512,230 @@ static bool stem_px_enabled() {                               // tuning hook (A/
     return v != 0;
 }
 
+
+// ---- matrix-core form for stems of 16..64 output channels (IResNet: 64) ------------------------------------------------------------
+// The LDS-tile kernel above is bound by its 27 x Cout scalar-operand FMAs and LDS reads (155 us for 128 faces, 411 MB written: 0.33 of
+// HBM).  Same construction as front_kernel's stem (dwpw_mfma.hip): per 16 output pixels one v_mfma_f32_16x16x32_bf16 shape per 16
+// output channels — rows = channels (A = weights as three bf16 terms whose sum is the fp32 weight exactly), columns = pixels (B = the 27
+// u8 taps of the 3 x 9-byte window, exact in bf16, 127.5 for the conv padding), fp32 accumulate; the result of the MFMA is pixel x 4
+// consecutive channels = one 16-byte store.  Persistent workgroups, a tile = 16 x 16 output pixels, its u8 window prefetched one tile
+// ahead into registers and parked in LDS, one LDS-only barrier per tile; per-channel vectors (bias, slope, s2, t2) in LDS so that no
+// global load sits between the stores.  Border tiles run a second, per-byte pass for the pixels whose window leaves the frame.
+__device__ __forceinline__ void stem_barrier() {                    // workgroup barrier that orders LDS traffic only (no vmcnt drain)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+typedef unsigned stem_v4u __attribute__((ext_vector_type(4)));
+typedef __bf16 stem_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int STRIDE, int CB>
+__global__ __launch_bounds__(256, 3) void stem_mfma_kernel(const uint8_t* __restrict__ src, long img_stride, int srcH, int srcW, int step, int inH,
+                                                           int inW, int Ho, int Wo, const unsigned* __restrict__ wfrag, const float* __restrict__ biasf,
+                                                           const float* __restrict__ slope, int act, float* __restrict__ out1,
+                                                           float* __restrict__ out2, const float* __restrict__ s2, const float* __restrict__ t2,
+                                                           int tiles_x, int tiles_y, int tiles_total) {
+    constexpr int S = STRIDE, T = STEM_TILE, COUT = CB * 16;
+    constexpr int ROWS = (T - 1) * S + 3;                                  // staged window rows
+    constexpr int PITCH = S == 1 ? 16 : 32;                                // dwords per staged row: ((T-1)*S + 3) * 3 + 3 bytes
+    constexpr int SLOTS = (ROWS * PITCH + 255) / 256;
+    static_assert(((T - 1) * S + 3) * 3 + 3 <= PITCH * 4, "staged row too narrow");
+    __shared__ unsigned stage[2][ROWS * PITCH];
+    __shared__ float cst[4][COUT];                                          // bias (folded), slope, s2, t2
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, lp = lane & 15;
+    const int row_bytes = srcW * 3;
+    if (tid < COUT) {
+        cst[0][tid] = biasf[tid];
+        cst[1][tid] = slope ? slope[tid] : 0.f;
+        cst[2][tid] = out2 ? s2[tid] : 0.f;
+        cst[3][tid] = out2 ? t2[tid] : 0.f;
+    }
+    stem_v4u wq[CB][3];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) wq[cb][q] = reinterpret_cast<const stem_v4u*>(wfrag)[(cb * 3 + q) * 64 + lane];
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) asm volatile("" ::"v"(wq[cb][0]), "v"(wq[cb][1]), "v"(wq[cb][2]));   // (the compiler's own wait for these loads: here)
+#endif
+    // a pixel's window lies inside the frame iff  AY0 <= oy <= AY1  and  AX0 <= ox <= AX1
+    const int AY0 = 1, AY1 = min(Ho - 1, (srcH - 2) / S), AX0 = (2 + S - 1) / S, AX1 = min(Wo - 1, (srcW - 3) / S);
+
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, wgs = gridDim.x >> 3;      // (gridDim.x is a multiple of 8)
+    const int q8 = tiles_total >> 3, r8 = tiles_total & 7;
+    const int run0 = xcd * q8 + min(xcd, r8), run1 = run0 + q8 + (xcd < r8 ? 1 : 0);
+    const int d_tx = wgs % tiles_x, d_ty = (wgs / tiles_x) % tiles_y, d_n = wgs / (tiles_x * tiles_y);
+    int t = run0 + wg;
+    int n = t / (tiles_x * tiles_y), tyi = (t / tiles_x) % tiles_y, txi = t % tiles_x;      // the tile being PREFETCHED
+    auto advance = [&]() {
+        txi += d_tx; if (txi >= tiles_x) { txi -= tiles_x; ++tyi; }
+        tyi += d_ty; if (tyi >= tiles_y) { tyi -= tiles_y; ++n; }
+        n += d_n;
+    };
+    unsigned pf[SLOTS];
+    const int pr = tid / PITCH, pd4 = (tid % PITCH) * 4;
+    auto prefetch = [&]() __attribute__((always_inline)) {
+        const uint8_t* frame = src + (size_t)n * img_stride;
+        const int sy0 = tyi * T * S - 1, sx3 = (txi * T * S - 1) * 3;
+        const unsigned base_lo = (unsigned)(unsigned long long)frame + (unsigned)(sy0 * step + sx3);
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int r = pr + (256 / PITCH) * k;
+            const unsigned shr = (base_lo + (unsigned)(r * step)) & 3u;
+            const int rel = sx3 - (int)shr + pd4;
+            const bool ok = r < ROWS && (unsigned)(sy0 + r) < (unsigned)srcH && rel >= 0 && rel + 4 <= row_bytes;
+            pf[k] = ok ? *(const gmem_u32*)(frame + (unsigned)((sy0 + r) * step + rel)) : 0u;
+        }
+    };
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    stem_barrier();
+    if (t < run1) prefetch();
+    int buf = 0;
+    for (; t < run1; t += wgs, buf ^= 1) {
+        const int cn = n, ty0 = tyi * T, tx0 = txi * T;
+        const uint8_t* frame = src + (size_t)cn * img_stride;
+        const int sy0 = ty0 * S - 1, sx0 = tx0 * S - 1;
+        const unsigned base_lo = (unsigned)(unsigned long long)frame + (unsigned)(sy0 * step + sx0 * 3);
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+            if (tid + 256 * k < ROWS * PITCH) stage[buf][tid + 256 * k] = pf[k];
+        advance();
+        if (t + wgs < run1) prefetch();
+        stem_barrier();
+        const unsigned* st = stage[buf];
+        const bool tile_inside = ty0 >= AY0 && ty0 + T - 1 <= AY1 && tx0 >= AX0 && tx0 + T - 1 <= AX1;
+        auto finish = [&](const float (&f)[8], bool store, int oy, int ox) __attribute__((always_inline)) {
+            stem_v4u bq;                                                   // fp32 -> bf16 by truncation: exact for 0..255 and 127.5
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                bq[i] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, f[2 * i + 1]), __builtin_bit_cast(unsigned, f[2 * i]), 0x07060302u);
+            const stem_bf16x8 bfrag = __builtin_bit_cast(stem_bf16x8, bq);
+            const size_t o = (((size_t)cn * Ho + oy) * Wo + ox) * COUT + 4 * g;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                v4f a4 = *reinterpret_cast<const v4f*>(&cst[0][cb * 16 + 4 * g]);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(stem_bf16x8, wq[cb][2]), bfrag, a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(stem_bf16x8, wq[cb][1]), bfrag, a4, 0, 0, 0);
+                a4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(stem_bf16x8, wq[cb][0]), bfrag, a4, 0, 0, 0);
+                if (act == 1) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a4[c] = a4[c] > 0.f ? a4[c] : 0.f;
+                } else if (act == 2) {
+                    const v4f sl = *reinterpret_cast<const v4f*>(&cst[1][cb * 16 + 4 * g]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a4[c] = a4[c] >= 0.f ? a4[c] : a4[c] * sl[c];
+                } else if (act == 3) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a4[c] = 1.0f / (1.0f + expf(-a4[c]));
+                }
+                if (store) {
+                    if (out1) *reinterpret_cast<v4f*>(out1 + o + cb * 16) = a4;
+                    if (out2) {
+                        const v4f sc = *reinterpret_cast<const v4f*>(&cst[2][cb * 16 + 4 * g]), sh = *reinterpret_cast<const v4f*>(&cst[3][cb * 16 + 4 * g]);
+                        *reinterpret_cast<v4f*>(out2 + o + cb * 16) = a4 * sc + sh;
+                    }
+                }
+            }
+        };
+        // FAST pass: wave w takes the tile rows w, w + 4, ...; lane = pixel lp of the row, K block g
+#pragma unroll
+        for (int i = 0; i < T / 4; ++i) {
+            const int py = wid + 4 * i;
+            const int oy = ty0 + py, ox = tx0 + lp;
+            const bool live = oy < Ho && ox < Wo;
+            const bool fast = live && (tile_inside || (oy >= AY0 && oy <= AY1 && ox >= AX0 && ox <= AX1));
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.f;
+            if (fast) {
+                const int cb3 = lp * S * 3;                                 // window's first byte relative to the staged row's first byte
+                if (g < 3) {
+                    const int rr = py * S + g;
+                    const unsigned pos = ((base_lo + (unsigned)(rr * step)) & 3u) + (unsigned)cb3;
+                    const unsigned* q = st + rr * PITCH + (pos >> 2);
+                    const unsigned sh = pos & 3u;
+                    const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
+                    const unsigned n0 = __builtin_amdgcn_alignbyte(d1, d0, sh), n1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                    f[0] = (float)(n0 & 255u); f[1] = (float)((n0 >> 8) & 255u); f[2] = (float)((n0 >> 16) & 255u); f[3] = (float)(n0 >> 24);
+                    f[4] = (float)(n1 & 255u); f[5] = (float)((n1 >> 8) & 255u); f[6] = (float)((n1 >> 16) & 255u); f[7] = (float)(n1 >> 24);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const int rr = py * S + r;
+                        const unsigned pos = ((base_lo + (unsigned)(rr * step)) & 3u) + (unsigned)(cb3 + 8);
+                        f[r] = (float)((st[rr * PITCH + (pos >> 2)] >> (8u * (pos & 3u))) & 255u);
+                    }
+                }
+            }
+            finish(f, fast, oy, ox);
+        }
+        if (!tile_inside) {
+            // BORDER pass: live pixels the FAST pass skipped — per byte; outside the net input = conv zero padding (127.5 cancels against
+            // the folded bias), inside it but outside the pasted image = letterbox canvas (u8 0)
+#pragma unroll 1
+            for (int i = 0; i < T / 4; ++i) {
+                const int py = wid + 4 * i;
+                const int oy = ty0 + py, ox = tx0 + lp;
+                const bool live = oy < Ho && ox < Wo;
+                const bool slow = live && !(oy >= AY0 && oy <= AY1 && ox >= AX0 && ox <= AX1);
+                const int iy0 = oy * S - 1, ix0 = ox * S - 1;
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = 0.f;
+                if (slow) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = g < 3 ? g : j, rb = g < 3 ? j : 8;
+                        if (g == 3 && j >= 3) continue;
+                        const int iy = iy0 + r, ix = ix0 + rb / 3;
+                        float b = 127.5f;
+                        if ((unsigned)iy < (unsigned)inH && (unsigned)ix < (unsigned)inW) {
+                            b = 0.f;
+                            if (iy < srcH && ix < srcW) b = (float)frame[(size_t)iy * step + (size_t)ix * 3 + rb % 3];
+                        }
+                        f[j] = b;
+                    }
+                }
+                finish(f, slow, oy, ox);
+            }
+        }
+    }
+}
+
+template <int STRIDE>
+static bool launch_stem_mfma(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int B, int inH, int inW, int Cout,
+                             const unsigned* wfrag, const float* biasf, const float* slope, int act, float* out1, float* out2, const float* s2,
+                             const float* t2, hipStream_t s) {
+    const int Ho = (inH + 2 - 3) / STRIDE + 1, Wo = (inW + 2 - 3) / STRIDE + 1;
+    const int tiles_x = (Wo + STEM_TILE - 1) / STEM_TILE, tiles_y = (Ho + STEM_TILE - 1) / STEM_TILE;
+    const int tiles_total = B * tiles_x * tiles_y;
+    if ((long)srcH * step >= (1L << 31)) return false;
+    const int grid = std::max(8, std::min((tiles_total + 7) / 8 * 8, conv_num_cus() * 3) / 8 * 8);
+#define FH_STEM_MFMA(CB)                                                                                                                   \
+    hipLaunchKernelGGL((stem_mfma_kernel<STRIDE, CB>), dim3(grid), dim3(256), 0, s, src, img_stride, srcH, srcW, step, inH, inW, Ho, Wo, wfrag, \
+                       biasf, slope, act, out1, out2, s2, t2, tiles_x, tiles_y, tiles_total)
+    switch (Cout) {
+        case 48: FH_STEM_MFMA(3); return true;
+        case 64: FH_STEM_MFMA(4); return true;
+        default: return false;
+    }
+#undef FH_STEM_MFMA
+}
+
 void launch_stem_conv_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int B, int inH, int inW, int stride,
                          int Cout, const float* w27, const float* bias, const float* wf, const float* biasf, const float* slope, int act,
-                         float* out1, float* out2, const float* s2, const float* t2, hipStream_t s) {
+                         float* out1, float* out2, const float* s2, const float* t2, hipStream_t s, const unsigned* wfrag) {
+    static const bool mfma_on = !(getenv("FACEHIP_STEM_MFMA") && atoi(getenv("FACEHIP_STEM_MFMA")) == 0);       // A/B switch
+    if (wfrag && biasf && mfma_on && Cout > 32) {                  // (16 / 32 channels: the thread-per-pixel kernel below is at its output-write bound)
+        if (stride == 1 ? launch_stem_mfma<1>(src, img_stride, srcH, srcW, step, B, inH, inW, Cout, wfrag, biasf, slope, act, out1, out2, s2, t2, s)
+                        : launch_stem_mfma<2>(src, img_stride, srcH, srcW, step, B, inH, inW, Cout, wfrag, biasf, slope, act, out1, out2, s2, t2, s))
+            return;
+    }
     if (wf && stem_px_enabled()) {
 #define FH_STEM_PX(S, C) launch_stem_px<S, C>(src, img_stride, srcH, srcW, step, B, inH, inW, w27, bias, wf, biasf, slope, act, out1, out2, s2, t2, s); return
         if (stride == 2 && Cout == 16) { FH_STEM_PX(2, 16); }
