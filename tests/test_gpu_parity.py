@@ -1325,3 +1325,33 @@ def test_folded_shortcut_matches_oracle_and_the_two_conv_form(tmp_path, ds_first
         r = oracle.run_graph(orec.g, {orec.g.inputs[0][0]: oracle.rec_preprocess(crops[i])[None]})[orec.g.outputs[0][0]].reshape(-1)
         for fold in (1, 0):
             np.testing.assert_allclose(got[fold][i], r, rtol=1e-4, atol=1e-4 * np.abs(r).max(), err_msg=f"fold={fold} slot {i}")
+
+
+@pytest.mark.parametrize("planes0,rows,cols,pitch", [(48, 90, 128, 384), (64, 128, 101, 101 * 3 + 2)])
+def test_matrix_core_stem_stride2_letterbox_and_odd_pitch(tmp_path, planes0, rows, cols, pitch):
+    """stem_mfma_kernel in the shapes no full-size model reaches: stride 2, 48 / 64 output channels (3 / 4 MFMA channel blocks), a
+    letterboxed frame and a frame whose row pitch is not a multiple of 4 (per-row misalignment of the staged window) — against the
+    separate preprocess + convolution form and against the oracle's heads."""
+    from facerecognizeonnx_amd.synth import models
+    path = models.make_scrfd(str(tmp_path / f"s{planes0}.onnx"), (1, 2, 1, 2), (planes0, 8, 16, 24, 32, 48), 8, 16, seed=21, cls_bias=-2.0,
+                             static_hw=128)
+    assert f"0 CONV k3s2 128x128x4 -> 64x64x{planes0}" in fa.plan_describe(path, 128, 128)
+    det = fa.FaceDetector(); odet = oracle.OracleDetector()
+    assert det.loadModel(path) and odet.loadModel(path)
+    img = np.zeros((2, rows, pitch), np.uint8)
+    img[:, :, :cols * 3] = util.frames_u8(2, rows, cols, seed=planes0).reshape(2, rows, cols * 3)
+    d = dev(img)
+    outs = []
+    for fused in (1, 0):
+        assert fa.lib().fh_det_set_fused_stem(det.handle, fused) == 0
+        assert fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), 2, rows, cols, pitch, rows * pitch, 0) == 2
+        torch.cuda.synchronize()
+        outs.append([o.copy() for o in _det_outputs(det, 2)])
+    for a, b in zip(*outs):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-5)
+    frame = np.ascontiguousarray(img[1, :, :cols * 3].reshape(rows, cols, 3))
+    inp, _ = oracle.det_preprocess(frame, 128, 128)
+    ref = odet.run_network(inp)
+    assert len(ref) == len(outs[0])
+    for a, r in zip(outs[0], ref):
+        np.testing.assert_allclose(a[1].reshape(-1), np.asarray(r).reshape(-1), rtol=1e-4, atol=1e-4)
