@@ -1,12 +1,13 @@
 #!/bin/bash
 # Runs on the GPU box: kernel-trace stats + HBM traffic counters for the default bench workload.
-# Usage: bash scripts/profile_round.sh r01
+# Usage: bash scripts/profile_round.sh r01 [bench.py args, e.g. --workload detect]
 TAG=${1:-r01}
+shift || true
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $OUT/fetch.err
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $OUT/write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing "$@" > /dev/null 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing "$@" > /dev/null 2> $OUT/write.err
 find $OUT -name "*.csv" | head -20
