@@ -79,7 +79,9 @@ def test_conv_layer_matches_oracle(B, H, W, Cin, Cout, k, stride, cfg):
 DWPW_CASES = [
     # H,  W,  C, Cout, depthwise stride   (maps large enough for the planner to fuse the pair; ragged tiles, channel
     #                                      counts off the 8 / 32 grid)
-    (40, 40, 16, 16, 1),
+    (40, 40, 16, 16, 1),                 # stem of 16 channels in front: front_kernel with a stride-1 stem
+    (45, 70, 16, 32, 1),                 # ... ragged tiles, row pitch 210 (not a multiple of 4), 32 output channels
+    (83, 61, 16, 24, 1),
     (41, 53, 20, 72, 1),
     (48, 40, 40, 40, 1),
     (44, 60, 72, 96, 1),
