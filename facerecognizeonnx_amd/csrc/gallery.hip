@@ -93,7 +93,6 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
     const int qrow = tid >> 4;
     const float* const q_base = p.q + (size_t)(n0 + qrow) * K + (((tid & 15) ^ (qrow & 15)) * 4);
     const size_t q16 = (size_t)16 * K;
-    v4f* const dstQ = &ldsq[0][wid * 64];
     const int fsw = fr & 15;
 
     for (int rt = rt0; rt < rt1; ++rt) {
@@ -103,11 +102,6 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
         const float* a_ptr = (live ? p.gal + (size_t)myrow * K : p.zeros) + fh2 * 4;       // dead rows read the zero line (and are masked below)
         const int a_step = live ? 64 : 0;
         const float* q_src = q_base;
-        auto load_q = [&](int buf) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gal_dma16(q_src + i * q16, dstQ + buf * (BN * 16) + i * 256);
-            q_src += 64;
-        };
         v4f xa[2][8];
         auto load_a = [&](v4f (&x)[8]) {
 #pragma unroll
@@ -133,18 +127,39 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
                     for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s][e], w[j][e], acc[j], 0, 0, 0);
             }
         };
+        // The query chunk goes global -> registers -> LDS (not by LDS-DMA): the compiler makes every LDS read wait for ALL vector-memory
+        // traffic while an LDS-DMA is in flight (it cannot tell the two halves of ldsq apart: `s_waitcnt vmcnt(0)` in front of each
+        // multiply, i.e. every chunk waited out its own gallery-row loads).  Through registers the dependencies are exact: the 4 query
+        // loads are issued BEFORE the 8 row loads, so the ds_write after the multiply waits with vmcnt(8) and the row loads fly on until
+        // the next barrier.  sched_barrier: left alone, the scheduler sinks the row loads below the multiply (one register set instead
+        // of two) and serialises them with it.
+        v4f qv[4];
+        auto fetch_q = [&]() {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qv[i] = *reinterpret_cast<const v4f*>(q_src + i * q16);
+            q_src += 64;
+        };
+        auto store_q = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ldsq[buf][i * 256 + tid] = qv[i];
+        };
         __syncthreads();                                   // previous tile's epilogue is done with the LDS lists / queues
+        fetch_q();
         load_a(xa[0]);
-        load_q(0);
+        store_q(0);
         int kc = 0;
         for (; kc + 2 <= chunks; kc += 2) {
-            __syncthreads();                               // queries of chunk kc landed (vmcnt(0) also covers xa[0]); buffer 1 is free
+            __syncthreads();                               // queries of chunk kc are in LDS (and xa[0] has landed: the barrier drains vmcnt)
+            fetch_q();
             load_a(xa[1]);
-            load_q(1);
+            __builtin_amdgcn_sched_barrier(0);
             multiply(xa[0], 0);
+            store_q(1);
             __syncthreads();
-            if (kc + 2 < chunks) { load_a(xa[0]); load_q(0); }
+            if (kc + 2 < chunks) { fetch_q(); load_a(xa[0]); }
+            __builtin_amdgcn_sched_barrier(0);
             multiply(xa[1], 1);
+            if (kc + 2 < chunks) store_q(0);
         }
         if (kc < chunks) {                                 // odd number of 64-deep chunks
             __syncthreads();
