@@ -687,7 +687,9 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
         if (!owners) {
             const long U = (long)R * chunks;
             int q = (int)((U + S - 1) / S);
-            const int min_q = chunks < 8 ? chunks : 8;          // do not cut segments shorter than 8 chunks
+            // do not cut segments shorter than 8 chunks — 24 for very deep K (the 25 088-deep FC: 61 slabs per tile made the fix-up kernel,
+            // 16 workgroups summing them one after the other, take 35 of the layer's 80 us; 21 slabs: 48 + 20 us)
+            const int min_q = chunks < 8 ? chunks : chunks >= 256 ? 24 : 8;
             if (q < min_q) q = min_q;
             const int maxp = (chunks + q - 1) / q + 1;
             if (q * sk_b_ratio() <= chunks * 2 && q < chunks && (size_t)R * maxp * BM * BN <= SK_SLAB_FLOATS) {
