@@ -103,6 +103,7 @@ PROTOTYPES = {
     "fh_rec_get_precision": (_i, [_vp]),
     "fh_det_set_cus": (_i, [_vp, _i]),
     "fh_rec_set_cus": (_i, [_vp, _i]),
+    "fh_debug_streamk": (_i, [_i, _i]),
     "fh_det_set_fused_stem": (_i, [_vp, _i]),
     "fh_rec_set_fused_stem": (_i, [_vp, _i]),
     "fh_det_set_fused_front": (_i, [_vp, _i]),

@@ -16,7 +16,11 @@ thread_local std::string g_err;
 template <class F>
 int guarded(F&& f) {
     try {
-        return f();
+        const int rc = f();
+        // stream-K watchdog (conv_mfma.hip): a launch whose hand-off timed out has reported through the host-mapped record by the
+        // time any later call gets here (the synchronous entry points: in this very call, after their own stream sync)
+        if (fh::conv_take_error(g_err)) return FH_ERR_DEVICE;
+        return rc;
     } catch (const std::exception& e) {
         g_err = e.what();
         const bool dev = g_err.rfind("HIP error", 0) == 0;
@@ -625,7 +629,9 @@ int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi, const float* d_
         dM.ensure(36 * (size_t)fh::wino_rows((long)tiles) * cout * sizeof(float));
         FH_HIP(hipMemcpy(dU.p, u36.data(), u36.size() * sizeof(float), hipMemcpyHostToDevice));
         static fh::DevBuf slabs;
-        if (!slabs.p) { slabs.ensure(fh::conv_slab_floats() * sizeof(float)); fh::conv_workspace_init(slabs.as<float>()); }
+        static unsigned slabs_gen = 0;
+        if (!slabs.p) { slabs.ensure(fh::conv_slab_floats() * sizeof(float)); fh::conv_workspace_init(slabs.as<float>()); slabs_gen = fh::conv_error_generation(); }
+        if (slabs_gen != fh::conv_error_generation()) { fh::conv_workspace_reset_async(slabs.as<float>(), S(stream)); slabs_gen = fh::conv_error_generation(); }
         fh::ConvArgs a{};
         a.in = d_in; a.bias = d_bias; a.out1 = d_out; a.slabs = slabs.as<float>(); a.sk_enable = 1;
         a.B = batch; a.H = h; a.W = w; a.Ho = h; a.Wo = w; a.Cin = cin; a.Cout = cout; a.ks = 3; a.stride = 1; a.pad = 1;
@@ -643,6 +649,7 @@ int fh_conv_pack_weights(const float* w_ohwi, int cout, int cin, int ksize, floa
     return 0;
 }
 int fh_conv_kpad(int ktot) { return fh::conv_kpad(ktot); }
+int fh_debug_streamk(int drop_publish, int timeout_ms) { fh::conv_debug_streamk(drop_publish, timeout_ms); return 0; }
 int fh_conv_forward_dev(const float* in, const float* wt, const float* bias, float* out, int batch, int h, int w, int cin, int cout,
                         int ks, int stride, int kpad, int cfg, void* stream) {
     if (!in || !wt || !out || batch <= 0 || (ks != 1 && ks != 3) || cin % 4) return arg_error("fh_conv_forward_dev: bad argument");
@@ -654,7 +661,9 @@ int fh_conv_forward_dev(const float* in, const float* wt, const float* bias, flo
         a.Ho = (h + 2 * pad - ks) / stride + 1; a.Wo = (w + 2 * pad - ks) / stride + 1;
         a.Kpad = kpad;
         static fh::DevBuf slabs;                 // test entry point only: one shared workspace
-        if (!slabs.p) { slabs.ensure(fh::conv_slab_floats() * sizeof(float)); fh::conv_workspace_init(slabs.as<float>()); }
+        static unsigned slabs_gen = 0;
+        if (!slabs.p) { slabs.ensure(fh::conv_slab_floats() * sizeof(float)); fh::conv_workspace_init(slabs.as<float>()); slabs_gen = fh::conv_error_generation(); }
+        if (slabs_gen != fh::conv_error_generation()) { fh::conv_workspace_reset_async(slabs.as<float>(), S(stream)); slabs_gen = fh::conv_error_generation(); }
         a.slabs = slabs.as<float>(); a.sk_enable = 1;
         fh::launch_conv(a, cfg, S(stream));
         FH_HIP(hipGetLastError());

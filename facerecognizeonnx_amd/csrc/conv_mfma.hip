@@ -37,7 +37,9 @@
 // owners: every segment goes to a slab and conv_fixup_kernel sums them in a second launch.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <stdexcept>
 
 #include "kernels.h"
@@ -285,6 +287,10 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
         c_end = p.sk_owner_chunks;
     }
     unsigned* const sk_counters = reinterpret_cast<unsigned*>(p.slabs + SK_SLAB_FLOATS);
+    // stream-K owner: "my hand-off wait timed out" flag.  The LAST word of the LDS images (free once the K loop is over, and beyond the
+    // 12 * BN floats the epilogue parks there) — a variable of its own would cost the 256x64 / 128x32 tiles a workgroup per CU
+    // (their images fill 80 / 40 KB exactly).
+    volatile int* const sk_gave_up = reinterpret_cast<volatile int*>(&lds[1][0]) + ((BM + BN) * 8 * 4 - 1);
 
     do {
         int part = 0;
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
                 // barrier, ONE lane releases at agent scope, waits, then bumps the tile's counter
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                if (tid == 0) {
+                if (tid == 0 && !p.sk_test_drop) {          // (sk_test_drop: the watchdog test's lost publication)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __hip_atomic_fetch_add(sk_counters + r, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -511,13 +517,32 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
             const int r = tile - p.sk_full;
             const int nparts = ((r + 1) * Kh - 1) / p.sk_q - (r * Kh) / p.sk_q + 1;
             if (tid == 0) {                                 // ONE lane polls relaxed, then ONE acquire
-                while (__hip_atomic_load(sk_counters + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)nparts)
+                // Bounded wait: forward progress rests on helpers (lower block indices) being dispatched before owners, which HIP
+                // does not promise.  Past sk_timeout (default 2 s of the constant 100 MHz clock — five orders of magnitude beyond any
+                // real wait) the owner gives up: it reports (tile, arrivals seen, arrivals expected) through the host-visible error
+                // record, leaves its tile unwritten and exits, so that the launch drains and the NEXT fh_* call returns
+                // FH_ERR_DEVICE instead of the process hanging with the GPU lease.
+                const unsigned long long t0 = wall_clock64();
+                unsigned seen, spins = 0;
+                bool arrived = true;
+                while ((seen = __hip_atomic_load(sk_counters + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != (unsigned)nparts) {
                     __builtin_amdgcn_s_sleep(4);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(sk_counters + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                    if ((++spins & 255u) == 0 && ((wall_clock64() - t0) >> 16) > (unsigned long long)p.sk_timeout) { arrived = false; break; }
+                }
+                if (arrived) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(sk_counters + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                } else if (p.sk_err) {
+                    __hip_atomic_store(p.sk_err + 1, (unsigned)tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(p.sk_err + 2, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(p.sk_err + 3, (unsigned)nparts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(p.sk_err + 0, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                *sk_gave_up = arrived ? 0 : 1;
             }
             __syncthreads();
+            if (*sk_gave_up) return;                        // (workgroup-uniform; an owner runs exactly one tile)
             for (int q = 0; q < nparts; ++q) {              // K order: own chunks first, then the helpers' runs
                 const float* slab = p.slabs + ((size_t)r * p.sk_maxp + q) * TL::SLAB;
 #pragma unroll
@@ -631,6 +656,36 @@ const float* conv_zero_line() {                      // 8 KiB of zeros: a padded
 
 size_t conv_slab_floats() { return SK_SLAB_FLOATS + SK_COUNTERS; }   // slabs + one counter word per remainder tile
 void conv_workspace_init(float* ws) { (void)hipMemset(ws + SK_SLAB_FLOATS, 0, SK_COUNTERS * sizeof(unsigned)); }
+void conv_workspace_reset_async(float* ws, hipStream_t s) { (void)hipMemsetAsync(ws + SK_SLAB_FLOATS, 0, SK_COUNTERS * sizeof(unsigned), s); }
+
+// ---- stream-K watchdog: a host-mapped (pinned, device-visible) record an owner writes when its hand-off wait times out
+static unsigned* g_sk_err = nullptr;
+static unsigned g_sk_generation = 0;
+static unsigned g_sk_timeout = (unsigned)((2000ull * 100000ull) >> 16);      // 2 s in units of 2^16 ticks of the 100 MHz wall clock
+static int g_sk_test_drop = 0;
+unsigned* conv_error_words() {
+    if (!g_sk_err) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) { memset(p, 0, 64); g_sk_err = (unsigned*)p; }
+    }
+    return g_sk_err;
+}
+bool conv_take_error(std::string& msg) {
+    volatile unsigned* e = g_sk_err;
+    if (!e || !e[0]) return false;
+    char buf[256];
+    snprintf(buf, sizeof buf, "HIP error: stream-K hand-off timed out (remainder tile %u saw %u of %u helper arrivals): the launch was "
+             "abandoned, its outputs are incomplete", e[1], e[2], e[3]);
+    msg = buf;
+    e[0] = 0;
+    ++g_sk_generation;                                   // every workspace's counters are suspect: owners re-zero them before their next run
+    return true;
+}
+unsigned conv_error_generation() { return g_sk_generation; }
+void conv_debug_streamk(int drop_publish, int timeout_ms) {
+    g_sk_test_drop = drop_publish;
+    g_sk_timeout = (unsigned)(((unsigned long long)(timeout_ms > 0 ? timeout_ms : 2000) * 100000ull) >> 16);
+}
 
 static int sk_b_ratio() {                              // fix-up form only when a tile is cut into >= ratio/2 pieces (tuning hook)
     static int v = -1;
@@ -700,6 +755,7 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
     }
     if (!helpers) { full = T; R = 0; }
     a.sk_full = full; a.sk_helpers = helpers; a.sk_rem = R;
+    a.sk_err = owners ? conv_error_words() : nullptr; a.sk_timeout = g_sk_timeout; a.sk_test_drop = g_sk_test_drop;
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
     const dim3 grid((unsigned)(full + helpers + owners));

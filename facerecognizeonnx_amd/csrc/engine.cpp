@@ -155,6 +155,7 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
                 probe.res_mode = (int)op.res_mode; probe.H = op.H; probe.W = op.W;
                 float dummy = 0.f;
                 probe.out2 = op.out2 >= 0 ? &dummy : nullptr;
+                probe.bias_cls = dev_[i].bn_fold_src >= 0 ? 1 : 0;   // (a BatchNorm-folded conv carries 9 bias classes: not a halo candidate)
                 if (conv_halo_ok(probe) && op.Ho * op.Wo >= 400) {
                     std::vector<float> wf(conv_halo_wfrag_floats(op.Cin, op.Cout));
                     conv_halo_pack_weights(op.weight.data(), op.Cout, op.Cin, wf.data());
@@ -196,6 +197,9 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
     for (size_t i = 0; i < plan_.ops.size(); ++i) {
         const POp& c = plan_.ops[i];
         if (c.sc_src < 0 || dev_[i].bn_fold_src >= 0 || c.bias.size() != (size_t)c.Cout) continue;
+        // the tenth tap only exists in the direct kernel (conv_mfma.hip): a consumer that may run in its Winograd or halo form
+        // (stride-1 projection blocks) keeps the two-convolution form, or the shortcut would silently vanish at large batches
+        if (dev_[i].wino || dev_[i].halo) continue;
         const POp& x = plan_.ops[c.sc_src];
         const int K9 = 9 * c.Cin, K = K9 + x.Cin, rows = conv_wt_rows(c.Cout);
         std::vector<float> w((size_t)rows * K, 0.f), b((size_t)c.Cout);
@@ -296,6 +300,7 @@ void Net::reserve(int max_batch) {
     if (partial_.bytes < conv_slab_floats() * sizeof(float)) {
         partial_.ensure(conv_slab_floats() * sizeof(float));
         conv_workspace_init(partial_.as<float>());
+        sk_gen_ = conv_error_generation();
     }
     if (wino_elems_) {
         const size_t pad = 36 * 256 * wino_maxc_;                // every frequency plane is padded to whole 256-row tiles
@@ -366,6 +371,10 @@ int Net::set_bf16x2(bool on, hipStream_t s) {
 
 void Net::run(int batch, hipStream_t s, int first_op) {
     if (batch <= 0) return;
+    if (sk_gen_ != conv_error_generation() && partial_.p) {   // a stream-K hand-off timed out somewhere since: late helper arrivals may have
+        conv_workspace_reset_async(partial_.as<float>(), s);  // left counters non-zero — re-zero them, stream-ordered, before the next launch
+        sk_gen_ = conv_error_generation();
+    }
     if (batch > cap_) throw std::runtime_error("Net::run: batch exceeds reserved capacity");
     const float* P = params_.as<float>();
     KernelTimer& timer = KernelTimer::get();

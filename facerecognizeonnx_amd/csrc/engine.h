@@ -92,6 +92,7 @@ class Net {
     size_t wino_maxc_ = 0;
     size_t wino_elems_ = 0;                                   // per image: 36 * tiles * max(Cin, Cout) of the largest Winograd op
     int cap_ = 0;
+    unsigned sk_gen_ = 0;                                     // conv_error_generation() this Net's hand-off counters were last zeroed under
     bool stem_ok_ = false;
     bool front_ok_ = false;                                   // ops 0 + 1 = stem conv (16 channels) -> DW+PW: one kernel
 };

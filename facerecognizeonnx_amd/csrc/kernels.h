@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <string>
 
 #include <vector>
 
@@ -89,12 +90,26 @@ struct ConvArgs {
     // filled in by launch_conv: #plain tiles, K-chunk units dealt to helpers, units per helper, #helpers, #remainder
     // tiles, chunks each owner computes itself (0 = no owners: fix-up kernel), slab slots per remainder tile
     int sk_full, sk_units, sk_q, sk_helpers, sk_rem, sk_owner_chunks, sk_maxp;
+    // stream-K watchdog (filled in by launch_conv): host-visible error record, the owners' wait bound in 2^16 ticks of the 100 MHz
+    // wall clock, and the test hook that makes helpers "lose" their publication
+    unsigned* sk_err;
+    unsigned sk_timeout;
+    int sk_test_drop;
 };
 
 // cfg: 0 = 128x128 tile, 1 = 256x64, 2 = 128x32, 3 = 64x64 (256 threads each); -1 = choose.
 void launch_conv(const ConvArgs& a, int cfg, hipStream_t s);
 int conv_pick_cfg(long M, int Cout);
 void conv_workspace_init(float* ws);          // zero the counter words of a freshly allocated stream-K workspace
+void conv_workspace_reset_async(float* ws, hipStream_t s);   // the same, stream-ordered (after a reported hand-off time-out)
+// Stream-K watchdog.  An owner workgroup whose helpers never arrive gives up after a bounded wait and reports through a host-mapped
+// record; conv_take_error() returns true once (with a message starting "HIP error") and bumps conv_error_generation(), after which
+// every Net re-zeroes its hand-off counters before its next run.  conv_debug_streamk(drop, ms): test hook — helpers skip their
+// publication / the owners' wait bound in milliseconds (0 = the 2 s default).
+unsigned* conv_error_words();
+bool conv_take_error(std::string& msg);
+unsigned conv_error_generation();
+void conv_debug_streamk(int drop_publish, int timeout_ms);
 const float* conv_zero_line();                // 8 KiB of device zeros (target of padded / dead loads)
 int conv_num_cus();                           // compute units of the current device
 // dense 3x3 stride-1 convolutions with 16 input channels and <= 64 output channels on an 8x16 spatial tile with an LDS halo

@@ -97,16 +97,35 @@ struct Val {
 
 // Identity and (inference-mode) Dropout nodes on tensors are pass-throughs: drop them, renaming their outputs to their inputs in
 // every later node and in the graph outputs.  Only the node list is copied (the initializers are shared by reference).
-static bool strip_passthrough(const OnnxModel& m, std::vector<OnnxNode>& nodes, std::vector<OnnxValueInfo>& outputs) {
+//
+// The same renaming covers an Identity whose input is an INITIALIZER: torch's exporter de-duplicates equal parameter tensors
+// (default-initialised BatchNorm / PReLU parameters, equal biases) into `Identity(initializer) -> alias` nodes, and ONNX Runtime
+// (reference src/face_detector.cpp:24-26) resolves those like any other node — every later use of the alias is pointed at the
+// initializer itself.  `Constant` nodes that carry a tensor (`value`) become initializers under their output name (`consts`), so that a
+// weight, slope or BatchNorm vector produced by a Constant is found by init_of() as well; scalar attribute forms (value_float /
+// value_int / value_ints / value_floats, opset >= 12) are turned into tensors first.
+static bool strip_passthrough(const OnnxModel& m, std::vector<OnnxNode>& nodes, std::vector<OnnxValueInfo>& outputs,
+                              std::map<std::string, OnnxTensor>& consts) {
     bool any = false;
-    for (const auto& n : m.nodes) any = any || ((n.op == "Identity" || n.op == "Dropout") && !n.inputs.empty() && !m.inits.count(n.inputs[0]));
+    for (const auto& n : m.nodes) any = any || n.op == "Identity" || n.op == "Dropout" || n.op == "Constant";
     if (!any) return false;
     std::map<std::string, std::string> alias;
     auto A = [&](const std::string& v) { auto it = alias.find(v); return it == alias.end() ? v : it->second; };
     for (const auto& n : m.nodes) {
-        if ((n.op == "Identity" || n.op == "Dropout") && !n.inputs.empty() && !m.inits.count(n.inputs[0]) && !n.outputs.empty()) {
+        if ((n.op == "Identity" || n.op == "Dropout") && !n.inputs.empty() && !n.outputs.empty()) {
             alias[n.outputs[0]] = A(n.inputs[0]);           // (a Dropout's optional mask output is never used at inference)
             continue;
+        }
+        if (n.op == "Constant" && !n.outputs.empty()) {
+            OnnxTensor t;
+            bool ok = true;
+            if (n.attrs.count("value")) t = n.attrs.at("value").t;
+            else if (n.attrs.count("value_float")) { t.dtype = 1; t.f = {n.attrs.at("value_float").f}; }
+            else if (n.attrs.count("value_int")) { t.dtype = 7; t.i = {n.attrs.at("value_int").i}; }
+            else if (n.attrs.count("value_floats")) { t.dtype = 1; t.f = n.attrs.at("value_floats").floats; t.dims = {(int64_t)t.f.size()}; }
+            else if (n.attrs.count("value_ints")) { t.dtype = 7; t.i = n.attrs.at("value_ints").ints; t.dims = {(int64_t)t.i.size()}; }
+            else ok = false;
+            if (ok) { t.name = n.outputs[0]; consts[n.outputs[0]] = std::move(t); continue; }
         }
         OnnxNode c = n;
         for (auto& i : c.inputs) i = A(i);
@@ -122,12 +141,14 @@ static Plan build_plan_impl(const OnnxModel& m, int inH, int inW);
 Plan build_plan(const OnnxModel& m0, int inH, int inW) {
     std::vector<OnnxNode> nodes;
     std::vector<OnnxValueInfo> outputs;
-    if (!strip_passthrough(m0, nodes, outputs)) return build_plan_impl(m0, inH, inW);
-    OnnxModel m;                                             // same graph without the pass-through nodes
+    std::map<std::string, OnnxTensor> consts;
+    if (!strip_passthrough(m0, nodes, outputs, consts)) return build_plan_impl(m0, inH, inW);
+    OnnxModel m;                                             // same graph without the pass-through / Constant nodes
     m.nodes = std::move(nodes);
     m.outputs = std::move(outputs);
     m.inputs = m0.inputs;
     m.inits = m0.inits;                                      // (copy: only taken for graphs that contain such nodes)
+    for (auto& kv : consts) m.inits[kv.first] = std::move(kv.second);
     Plan P = build_plan_impl(m, inH, inW);
     for (size_t i = 0; i < P.outputs.size() && i < m0.outputs.size(); ++i) P.outputs[i].name = m0.outputs[i].name;   // keep the file's output names
     return P;

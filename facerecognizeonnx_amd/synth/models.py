@@ -62,7 +62,7 @@ def _fold(w, b, bn):
 def make_iresnet(path: str, layers: Sequence[int] = (3, 4, 14, 3),
                  widths: Sequence[int] = (64, 128, 256, 512), size: int = 112,
                  feat: int = 512, seed: int = 200, fold_bn: bool = True,
-                 batch_dim="N", downsample_first: bool = False) -> str:
+                 batch_dim="N", downsample_first: bool = False, stage_strides: Sequence[int] = (2, 2, 2, 2)) -> str:
     """IResNet as arcface_torch builds it.
 
     fold_bn=True ships Conv(+bias) where a BN follows a conv (as the public file does);
@@ -70,6 +70,8 @@ def make_iresnet(path: str, layers: Sequence[int] = (3, 4, 14, 3),
     exercised as well.  The pre-conv ``bn1`` of each block and the tail BNs always stay.
     downsample_first=True writes a block's shortcut convolution in front of its bn1 / conv1 nodes (a legal
     topological order some exporters produce): the block input then has its last listed reader BEFORE conv1.
+    stage_strides: stride of each stage's first block (arcface_torch: 2 everywhere); 1 gives a stride-1 block with a 1x1 PROJECTION
+    shortcut — a shape torchvision-style ResNets have and the engine's shortcut folding must not mistake for the strided one.
     """
     W = _W(seed)
     b = OnnxBuilder("iresnet")
@@ -106,7 +108,7 @@ def make_iresnet(path: str, layers: Sequence[int] = (3, 4, 14, 3),
     cin = widths[0]
     for li, (nblk, planes) in enumerate(zip(layers, widths)):
         for bi in range(nblk):
-            stride = 2 if bi == 0 else 1
+            stride = stage_strides[li] if bi == 0 else 1
             tag = f"layer{li + 1}.{bi}"
             sc = None
             if bi == 0 and downsample_first:
@@ -123,7 +125,9 @@ def make_iresnet(path: str, layers: Sequence[int] = (3, 4, 14, 3),
             cin = planes
     x = bn_node(x, cin, "bn2")
     x = b.node("Flatten", [x], axis=1)
-    sp = size // 16
+    sp = size
+    for st in stage_strides:
+        sp = (sp - 1) // st + 1
     kdim = cin * sp * sp
     wfc = (W.rng.standard_normal((feat, kdim)) * np.sqrt(1.0 / kdim)).astype(np.float32)
     x = b.node("Gemm", [x, b.init("fc.weight", wfc), b.init("fc.bias", W.bias(feat))],

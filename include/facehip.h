@@ -241,6 +241,10 @@ FH_API int fh_conv_forward_dev(const float* d_in, const float* d_wt_packed, cons
  * [cout][3*3][cin]; cin % 32 == 0, cout % 4 == 0.  Synchronous. */
 FH_API int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi_host, const float* d_bias, float* d_out, int batch, int h, int w,
                                 int cin, int cout, void* stream);
+/* Stream-K watchdog test hook (conv_mfma.hip): drop_publish != 0 makes the helper workgroups of a remainder round "lose" their
+ * publication, timeout_ms bounds the owners' wait (0 = the 2 s default).  An owner whose wait times out abandons its tile and the
+ * next fh_* call returns FH_ERR_DEVICE ("stream-K hand-off timed out ...") instead of the process hanging with the GPU. */
+FH_API int fh_debug_streamk(int drop_publish, int timeout_ms);
 FH_API int fh_conv_wt_rows(int cout);
 /* host: weights [cout][ksize*ksize][cin] (O,H,W,I) -> the kernel's packed image [fh_conv_wt_rows][fh_conv_kpad] */
 FH_API int fh_conv_pack_weights(const float* w_ohwi, int cout, int cin, int ksize, float* dst_packed);

@@ -720,8 +720,9 @@ def _records(t, n, per):
 @pytest.mark.parametrize("B", [128, 256])
 def test_r50_headline_batch_winograd_matches_oracle(B):
     """IResNet-50 at the batch sizes of the headline (128) and of config C2 (256): every 3x3 stride-1 layer with >= 128 input
-    channels runs in its Winograd form here (7x7x512 included — it needs B >= 64), which n = 3 never reaches.  Three slots
-    (first, middle, last) against the oracle's direct fp32 evaluation (face_recognizer.cpp:279-297)."""
+    channels runs in its Winograd form here (7x7x512 included — it needs B >= 64), which n = 3 never reaches.  Sixteen slots
+    spread over the batch (first and last included: every 128-row GEMM tile position, both halves of the stream-K remainder round)
+    against the oracle's direct fp32 evaluation (face_recognizer.cpp:279-297)."""
     from facerecognizeonnx_amd.synth import models
     path = models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
     rec = fa.FaceRecognizer(); orec = oracle.OracleRecognizer()
@@ -732,7 +733,8 @@ def test_r50_headline_batch_winograd_matches_oracle(B):
     torch.cuda.synchronize()
     got, graw = out.cpu().numpy(), raw.cpu().numpy()
     assert np.isfinite(got).all()
-    for i in (0, B // 2, B - 1):
+    oracle.set_threads(min(16, os.cpu_count() or 8))
+    for i in sorted({int(round(x)) for x in np.linspace(0, B - 1, 16)}):
         inp = oracle.rec_preprocess(crops[i])
         r = oracle.run_graph(orec.g, {orec.g.inputs[0][0]: inp[None]})[orec.g.outputs[0][0]].reshape(-1)
         ref = oracle.l2_normalize(r)
