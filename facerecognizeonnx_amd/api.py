@@ -74,12 +74,14 @@ class FaceDetector:
         return bool(self._h)
 
     def detect_records(self, image, scoreThreshold: float = 0.5, nmsThreshold: float = 0.4,
-                       max_faces: int = 4096) -> np.ndarray:
+                       max_faces: Optional[int] = None) -> np.ndarray:
         if not self._h:
             return np.zeros(0, FACE_DTYPE)                            # "Model not loaded!" :142-145
         a = _img(image)
         if a is None:
             return np.zeros(0, FACE_DTYPE)                            # :148-156
+        if max_faces is None:                                         # the reference's std::vector is unbounded: every candidate row can survive
+            max_faces = max(1, self.num_anchors())
         out = np.zeros(max_faces, FACE_DTYPE)
         n = check(_lib.lib().fh_det_detect(self._h, a.ctypes.data, a.shape[0], a.shape[1], a.strides[0],
                                             scoreThreshold, nmsThreshold, out.ctypes.data, max_faces), "fh_det_detect")

@@ -214,7 +214,15 @@ int fh_postprocess_rows_dev(const float* rows, int n, int rows_per_frame, int fe
             FH_HIP(hipMemsetAsync(counts, 0, (size_t)n * sizeof(int), s));
             return n;
         }
-        static fh::DevBuf cand, keys, ws, count;
+        // scratch of this entry point: one set per calling thread, and a call on a DIFFERENT stream than the previous one first waits
+        // for that one's kernels (event), so overlapping calls cannot race on cand / keys / ws / count.  Heap-allocated and never
+        // destroyed: a static DevBuf's destructor would call hipFree after the HIP runtime has been torn down at process exit.
+        struct Scratch { fh::DevBuf cand, keys, ws, count; hipEvent_t done = nullptr; hipStream_t last = nullptr; bool used = false; };
+        thread_local Scratch* scp = new Scratch();
+        Scratch& sc = *scp;
+        if (!sc.done) FH_HIP(hipEventCreateWithFlags(&sc.done, hipEventDisableTiming));
+        if (sc.used && sc.last != s) FH_HIP(hipStreamWaitEvent(s, sc.done, 0));
+        fh::DevBuf &cand = sc.cand, &keys = sc.keys, &ws = sc.ws, &count = sc.count;
         int cap = 1;
         while (cap < rows_per_frame) cap <<= 1;                           // the in-place bitonic sort needs a power of two
         cand.ensure((size_t)n * cap * sizeof(fh::FaceRec));
@@ -227,6 +235,8 @@ int fh_postprocess_rows_dev(const float* rows, int n, int rows_per_frame, int fe
         fh::launch_sort_nms(cand.as<fh::FaceRec>(), keys.as<unsigned long long>(), count.as<int>(), cap, n, nms_thr,
                             reinterpret_cast<fh::FaceRec*>(out), counts, max_pf, ws.as<int>(), s);
         FH_HIP(hipGetLastError());
+        FH_HIP(hipEventRecord(sc.done, s));
+        sc.last = s; sc.used = true;
         return n;
     });
 }
@@ -552,6 +562,9 @@ int fh_rec_set_precision(fh_rec* r, int mode, float* worst_out) {
         r->rec.embed_aligned_dev(dc.as<uint8_t>(), n, de.as<float>(), nullptr);
         const int layers = net.set_bf16x2(true, nullptr);
         if (layers == 0) { net.set_bf16x2(was, nullptr); throw std::runtime_error("fh_rec_set_precision: this model has no layer with a split-bf16 form"); }
+        // from here to the gate the handle is in the mode it has NOT yet been admitted to: anything that throws (the second embed, the
+        // synchronise, the read-back) must leave it fp32, as the header promises — the mode is committed only after `worst < gate`
+        struct Rollback { fh::Net& n; bool armed = true; ~Rollback() { if (armed) { try { n.set_bf16x2(false, nullptr); } catch (...) {} } } } rollback{net};
         r->rec.embed_aligned_dev(dc.as<uint8_t>(), n, de.as<float>() + (size_t)n * dim, nullptr);
         std::vector<float> e((size_t)2 * n * dim);
         FH_HIP(hipDeviceSynchronize());
@@ -569,11 +582,10 @@ int fh_rec_set_precision(fh_rec* r, int mode, float* worst_out) {
         if (worst_out) *worst_out = (float)worst;
         double gate = 1e-3;                                             // FACEHIP_PRECISION_GATE may only TIGHTEN it (tests of the refusal path)
         if (const char* g = getenv("FACEHIP_PRECISION_GATE")) gate = std::min(gate, atof(g));
-        if (!(worst < gate)) {
-            net.set_bf16x2(false, nullptr);
+        if (!(worst < gate))                                            // (the guard above puts the handle back to fp32)
             throw std::runtime_error("fh_rec_set_precision: split-bf16 embeddings differ from fp32 by 1 - cos = " + std::to_string(worst) +
                                  " (gate " + std::to_string(gate) + "): staying fp32");
-        }
+        rollback.armed = false;
         return layers;
     });
 }

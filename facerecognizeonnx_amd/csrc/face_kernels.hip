@@ -311,7 +311,7 @@ void launch_sort_nms(const FaceRec* cand, unsigned long long* keys, const int* c
 // One workgroup per face.  ok: 1 = warped, 2 = fallback crop, 0 = empty result.
 // ------------------------------------------------------------------------------------------
 __device__ int estimate_similarity5(const float* from, const float* to, double* M) {
-    int best_cnt = 0; double best_err = 0; unsigned best_mask = 0;
+    int best_cnt = 0; unsigned best_mask = 0;
     for (int i = 0; i < 5; ++i)
         for (int j = i + 1; j < 5; ++j) {
             const double x1 = from[2 * i], y1 = from[2 * i + 1], x2 = from[2 * j], y2 = from[2 * j + 1];
@@ -324,15 +324,17 @@ __device__ int estimate_similarity5(const float* from, const float* to, double* 
             const double b = (dY * dx - dX * dy) / den;
             const double tx = X1 - (a * x1 - b * y1);
             const double ty = Y1 - (b * x1 + a * y1);
-            int cnt = 0; double esum = 0; unsigned mask = 0;
+            int cnt = 0; unsigned mask = 0;
             for (int p = 0; p < 5; ++p) {
                 const double fx = from[2 * p], fy = from[2 * p + 1];
                 const double ex = (a * fx - b * fy + tx) - to[2 * p];
                 const double ey = (b * fx + a * fy + ty) - to[2 * p + 1];
                 const double e = ex * ex + ey * ey;
-                if (e <= 9.0) { ++cnt; esum += e; mask |= 1u << p; }
+                if (e <= 9.0) { ++cnt; mask |= 1u << p; }
             }
-            if (cnt > best_cnt || (cnt == best_cnt && cnt > 0 && esum < best_err)) { best_cnt = cnt; best_err = esum; best_mask = mask; }
+            // strictly more inliers, else the EARLIER pair stays (OpenCV's registrator only replaces on a larger count; an error-sum
+            // tie-break would compare the rounding noise of a two-point consensus)
+            if (cnt > best_cnt) { best_cnt = cnt; best_mask = mask; }
         }
     if (best_cnt < 2) return 0;
     double mx = 0, my = 0, mu = 0, mv = 0;
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const int e = j * 256 + tid;
-            es[j] = -2.0f; ei[j] = -1;
+            es[j] = -INFINITY; ei[j] = -1;
             if (e < total) {
                 const int part = e / k, pos = e - part * k;
                 const size_t o = ((size_t)part * Q + q) * k + pos;
@@ -491,14 +493,14 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
             }
         }
     }
-    float last_s = 0.f; int last_i = -1; bool have_last = false;
+    float last_s = 0.f; int last_i = -1; bool have_last = false, exhausted = false;
     for (int round = 0; round < k; ++round) {
-        float best_s = -2.0f; int best_i = 0x7fffffff;
+        float best_s = -INFINITY; int best_i = 0x7fffffff;                   // (emptiness is told by the index, not by the score: rows need not be unit vectors)
         if (CACHED) {
 #pragma unroll
             for (int j = 0; j < E; ++j) {
                 const float sc = es[j]; const int gi = ei[j];
-                const bool ok = gi >= 0 && (!have_last || better(last_s, last_i, sc, gi)) && better(sc, gi, best_s, best_i);
+                const bool ok = !exhausted && gi >= 0 && (!have_last || better(last_s, last_i, sc, gi)) && better(sc, gi, best_s, best_i);
                 best_s = ok ? sc : best_s; best_i = ok ? gi : best_i;
             }
 #pragma unroll
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
                 const int part = e / k, pos = e - part * k;
                 const size_t o = ((size_t)part * Q + q) * k + pos;
                 const float sc = ps[o]; const int gi = pi[o];
-                if (gi < 0) continue;
+                if (gi < 0 || exhausted) continue;
                 if (have_last && !better(last_s, last_i, sc, gi)) continue;     // must come strictly after the last pick
                 if (better(sc, gi, best_s, best_i)) { best_s = sc; best_i = gi; }
             }
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
             out_s[(size_t)q * k + round] = found ? last_s : -1.0f;
             out_i[(size_t)q * k + round] = found ? last_i : -1;
         }
-        if (last_i == 0x7fffffff) { last_s = -3.0f; }   // nothing left: later rounds find nothing either
+        if (last_i == 0x7fffffff) exhausted = true;      // nothing left: later rounds find nothing either (workgroup-uniform)
     }
 }
 

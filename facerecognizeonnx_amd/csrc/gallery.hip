@@ -78,9 +78,9 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
     float ls[GAL_KMAX];                                       // thread q < 64: sorted list of query q (entries >= k stay sentinels)
     int li[GAL_KMAX];
 #pragma unroll
-    for (int i = 0; i < GAL_KMAX; ++i) { ls[i] = -1.0f; li[i] = INT_MAX; }
+    for (int i = 0; i < GAL_KMAX; ++i) { ls[i] = -INFINITY; li[i] = INT_MAX; }
     if (tid < BN) {
-        float ts = -1.0f; int ti = INT_MAX;                       // (-1, INT_MAX): below every real entry (scores are in [0, 1])
+        float ts = -INFINITY; int ti = INT_MAX;                   // (-inf, INT_MAX): below every real entry, whatever the rows' norms (compareFaces does not clamp, face_recognizer.cpp:320-334)
         if (p.seed_i && n0 + tid < p.Q) {
             const size_t o = (size_t)(n0 + tid) * k + (k - 1);
             if (p.seed_i[o] >= 0) { ts = p.seed_s[o]; ti = p.seed_i[o]; }

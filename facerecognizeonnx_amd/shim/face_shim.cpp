@@ -16,7 +16,6 @@
 
 namespace {
 bool verbose() { const char* v = std::getenv("FACEHIP_VERBOSE"); return v && *v && *v != '0'; }
-constexpr int kMaxFaces = 4096;
 }  // namespace
 
 FaceDetector::FaceDetector() : h_(nullptr) {}
@@ -46,8 +45,11 @@ std::vector<FaceBox> FaceDetector::detect(const cv::Mat& image, float scoreThres
     std::vector<FaceBox> faces;
     if (!h_) { std::cerr << "Model not loaded!" << std::endl; return faces; }
     if (image.empty()) { std::cerr << "Input image is empty!" << std::endl; return faces; }
-    std::vector<fh_face> buf(kMaxFaces);
-    const int n = fh_det_detect(h_, image.data, image.rows, image.cols, (int)image.step, scoreThreshold, nmsThreshold, buf.data(), kMaxFaces);
+    // the reference returns every post-NMS box (std::vector, src/face_detector.cpp:376-383): size the buffer for the case that
+    // every candidate row survives (16 800 anchors for det_500m) instead of truncating at a fixed count
+    const int cap = fh_det_num_anchors(h_) > 0 ? fh_det_num_anchors(h_) : 16800;
+    std::vector<fh_face> buf((size_t)cap);
+    const int n = fh_det_detect(h_, image.data, image.rows, image.cols, (int)image.step, scoreThreshold, nmsThreshold, buf.data(), cap);
     if (n < 0) { std::cerr << "Error during inference: " << fh_last_error() << std::endl; return faces; }
     faces.resize((size_t)n);
     for (int i = 0; i < n; ++i) {

@@ -247,11 +247,14 @@ ORC_API void orc_resize_bilinear_u8c3(const uint8_t* src, int sh, int sw, int ss
  * inliers (squared error <= 9) and refines it on those inliers; the 4-DoF model is linear,
  * so the refinement converges to the closed-form least squares over the inlier set.  With 5
  * points the sample space is the C(5,2)=10 pairs, which are enumerated exhaustively here:
- * best = most inliers, then smallest inlier error sum, then first pair.  "RANSAC-equivalent,
- * not RNG-identical" (SURVEY.md B.3).  M = [[a,-b,tx],[b,a,ty]] (double).  Returns 0 when
+ * best = most inliers, then FIRST pair in (i < j) order — OpenCV's registrator replaces its
+ * best model only on a STRICTLY larger inlier count, so among equals the earliest sample stays.
+ * (Rounds 1-2 broke such ties by the smaller inlier error sum; for a two-point consensus that
+ * sum is rounding noise around 1e-25, and a 3e-5 px landmark difference chose another model:
+ * found by the round-3 composition test.)  "RANSAC-equivalent, not RNG-identical" (SURVEY.md B.3).  M = [[a,-b,tx],[b,a,ty]] (double).  Returns 0 when
  * no pair of distinct source points exists (OpenCV returns an empty Mat). */
 ORC_API int orc_estimate_similarity5(const float* from, const float* to, double* M) {
-    int best_cnt = 0; double best_err = 0; unsigned best_mask = 0;
+    int best_cnt = 0; unsigned best_mask = 0;
     for (int i = 0; i < 5; ++i)
         for (int j = i + 1; j < 5; ++j) {
             const double x1 = from[2 * i], y1 = from[2 * i + 1], x2 = from[2 * j], y2 = from[2 * j + 1];
@@ -264,17 +267,15 @@ ORC_API int orc_estimate_similarity5(const float* from, const float* to, double*
             const double b = (dY * dx - dX * dy) / den;
             const double tx = X1 - (a * x1 - b * y1);
             const double ty = Y1 - (b * x1 + a * y1);
-            int cnt = 0; double esum = 0; unsigned mask = 0;
+            int cnt = 0; unsigned mask = 0;
             for (int p = 0; p < 5; ++p) {
                 const double fx = from[2 * p], fy = from[2 * p + 1];
                 const double ex = (a * fx - b * fy + tx) - to[2 * p];
                 const double ey = (b * fx + a * fy + ty) - to[2 * p + 1];
                 const double e = ex * ex + ey * ey;
-                if (e <= 9.0) { ++cnt; esum += e; mask |= 1u << p; }
+                if (e <= 9.0) { ++cnt; mask |= 1u << p; }
             }
-            if (cnt > best_cnt || (cnt == best_cnt && cnt > 0 && esum < best_err)) {
-                best_cnt = cnt; best_err = esum; best_mask = mask;
-            }
+            if (cnt > best_cnt) { best_cnt = cnt; best_mask = mask; }
         }
     if (best_cnt < 2) return 0;
     double mx = 0, my = 0, mu = 0, mv = 0;
