@@ -4,6 +4,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "../../include/facehip.h"
 #include "engine.h"
@@ -41,10 +42,78 @@ namespace fh {
 void set_error(const std::string& msg) { g_err = msg; }      // for the other translation units of the C ABI
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Batch-1 host-pointer calls (fh_det_detect / fh_rec_extract / fh_rec_extract_simple = the reference's own mode: one image per
+// call, src/face_detector.cpp:170, src/face_recognizer.cpp:270, callers src/main.cpp:88-104) are ~100 short kernels each: issued
+// eagerly they are bound by the host's launch rate (~3.5 us per launch), not by the GPU.  The whole call — H2D of the image from a
+// pinned staging buffer, every kernel, D2H of the results into a pinned landing buffer — is therefore captured ONCE per call shape
+// into a HIP graph and replayed: one hipGraphLaunch + one stream synchronise per call.  The first call with a new shape runs
+// eagerly (it sizes every device buffer: nothing may allocate during capture), the second captures, later ones replay.  Same
+// kernels, same order, same arguments: results are bitwise those of the eager path (tests/test_gpu_round3.py).
+struct PinnedBuf {
+    void* p = nullptr; size_t bytes = 0;
+    bool ensure(size_t n) {                                   // returns true when the buffer moved (a captured graph holds the old address)
+        if (n <= bytes) return false;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; bytes = 0;
+        FH_HIP(hipHostMalloc(&p, n, hipHostMallocDefault));
+        bytes = n;
+        return true;
+    }
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+};
+bool g_graph_replay = [] { const char* e = getenv("FACEHIP_GRAPH"); return !e || atoi(e) != 0; }();
+struct GraphCall {
+    hipGraph_t g = nullptr; hipGraphExec_t x = nullptr;
+    std::vector<long long> key;
+    int seen = 0;
+    size_t nodes = 0;
+    long replays = 0;
+    void reset() {
+        if (x) (void)hipGraphExecDestroy(x);
+        if (g) (void)hipGraphDestroy(g);
+        x = nullptr; g = nullptr; seen = 0; nodes = 0;
+    }
+    ~GraphCall() { reset(); }
+    // body(stream) enqueues the whole call on `stream` (async copies + kernels, no host synchronisation, no allocation once warm)
+    template <class F>
+    void run(const std::vector<long long>& k, hipStream_t s, F&& body) {
+        const bool allow = g_graph_replay && !fh::KernelTimer::get().enabled && !getenv("FACEHIP_DEBUG_SYNC");
+        if (!allow) { reset(); key.clear(); body(s); return; }
+        if (k != key) { reset(); key = k; }
+        if (x) { FH_HIP(hipGraphLaunch(x, s)); ++replays; return; }
+        if (seen++ == 0) { body(s); return; }
+        FH_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        try {
+            body(s);
+        } catch (...) {
+            hipGraph_t dead = nullptr;
+            (void)hipStreamEndCapture(s, &dead);
+            if (dead) (void)hipGraphDestroy(dead);
+            seen = 0;
+            throw;
+        }
+        FH_HIP(hipStreamEndCapture(s, &g));
+        FH_HIP(hipGraphInstantiate(&x, g, nullptr, nullptr, 0));
+        (void)hipGraphGetNodes(g, nullptr, &nodes);
+        FH_HIP(hipGraphLaunch(x, s));
+        ++replays;
+    }
+};
+struct CallStream {                                         // the handle's own stream for the host-pointer calls (capture needs a non-null stream)
+    hipStream_t s = nullptr;
+    hipStream_t get() { if (!s) FH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return s; }
+    ~CallStream() { if (s) (void)hipStreamDestroy(s); }
+};
+constexpr int kGraphFaces = 256;                            // records copied back inside the graph; a call with more fetches the rest eagerly
+
 struct fh_det {
     explicit fh_det(const char* p) : det(p) {}
     fh::Detector det;
     fh::DevBuf img, out, cnt;            // staging for the host-pointer API
+    PinnedBuf h_img, h_res;              // pinned source of the image upload / landing zone of [count | first kGraphFaces records]
+    GraphCall gcall;                     // (declared after the buffers: destroyed first)
+    CallStream cs;
     fh::DevBuf p_det, p_cnt, p_total;    // pipeline scratch
     hipEvent_t ev_sel = nullptr;         // detect -> embed hand-off (face count known / stream_rec may start)
     int* h_total = nullptr;              // pinned landing word of the face count
@@ -54,6 +123,9 @@ struct fh_rec {
     explicit fh_rec(const char* p) : rec(p) {}
     fh::Recognizer rec;
     fh::DevBuf img, face, emb;
+    PinnedBuf h_img, h_io;               // pinned image source; [fh_face in | ok flag + embedding out]
+    GraphCall gcall, gcall_simple;
+    CallStream cs;
 };
 struct fh_gallery {
     explicit fh_gallery(int dim) : g(dim) {}
@@ -164,22 +236,40 @@ int fh_det_detect(fh_det* d, const uint8_t* bgr, int rows, int cols, int step, f
     if (!bgr || rows <= 0 || cols <= 0) return 0;                        // :148-156 -> empty result
     if (!out || max_out <= 0 || step < cols * 3) return arg_error("fh_det_detect: bad output buffer / step");
     return guarded([&] {
-        const size_t bytes = (size_t)rows * step;
+        const size_t bytes = (size_t)rows * step, used = host_image_bytes(rows, cols, step);
+        const int in_graph = max_out < kGraphFaces ? max_out : kGraphFaces;
         d->img.ensure(bytes);
         d->out.ensure((size_t)max_out * sizeof(fh_face));
         d->cnt.ensure(sizeof(int));
-        FH_HIP(hipMemcpy(d->img.p, bgr, host_image_bytes(rows, cols, step), hipMemcpyHostToDevice));
+        const bool m1 = d->h_img.ensure(bytes), m2 = d->h_res.ensure(64 + (size_t)kGraphFaces * sizeof(fh_face));
+        const bool moved = m1 || m2;
+        if (moved) d->gcall.reset();
+        memcpy(d->h_img.p, bgr, used);                                        // pageable -> pinned (what hipMemcpy would do internally)
+        hipStream_t s = d->cs.get();
+        int* const h_cnt = static_cast<int*>(d->h_res.p);
+        fh_face* const h_faces = reinterpret_cast<fh_face*>(static_cast<char*>(d->h_res.p) + 64);
+        long long kthr, knms;
+        { float f = score_thr; int v; memcpy(&v, &f, 4); kthr = v; f = nms_thr; memcpy(&v, &f, 4); knms = v; }
+        const std::vector<long long> key{rows, cols, step, kthr, knms, max_out, (long long)(size_t)d->img.p, (long long)(size_t)d->out.p};
         try {
-            d->det.detect_dev(d->img.as<uint8_t>(), 1, rows, cols, step, (long)bytes, score_thr, nms_thr, d->out.as<fh::FaceRec>(),
-                              max_out, d->cnt.as<int>(), nullptr);
+            d->gcall.run(key, s, [&](hipStream_t st) {
+                FH_HIP(hipMemcpyAsync(d->img.p, d->h_img.p, used, hipMemcpyHostToDevice, st));
+                d->det.detect_dev(d->img.as<uint8_t>(), 1, rows, cols, step, (long)bytes, score_thr, nms_thr, d->out.as<fh::FaceRec>(),
+                                  max_out, d->cnt.as<int>(), st);
+                FH_HIP(hipMemcpyAsync(h_cnt, d->cnt.p, sizeof(int), hipMemcpyDeviceToHost, st));
+                FH_HIP(hipMemcpyAsync(h_faces, d->out.p, (size_t)in_graph * sizeof(fh_face), hipMemcpyDeviceToHost, st));
+            });
         } catch (const std::runtime_error& e) {
             if (std::string(e.what()) == "Invalid resize dimensions") return 0;   // :109-113,164-167
             throw;
         }
-        int c = 0;
-        FH_HIP(hipMemcpy(&c, d->cnt.p, sizeof(int), hipMemcpyDeviceToHost));
+        FH_HIP(hipStreamSynchronize(s));
+        int c = *h_cnt;
         c = c < max_out ? c : max_out;
-        if (c > 0) FH_HIP(hipMemcpy(out, d->out.p, (size_t)c * sizeof(fh_face), hipMemcpyDeviceToHost));
+        const int first = c < in_graph ? c : in_graph;
+        if (first > 0) memcpy(out, h_faces, (size_t)first * sizeof(fh_face));
+        if (c > first)                                                        // rare: more faces than the graph's landing zone holds
+            FH_HIP(hipMemcpy(out + first, d->out.as<fh_face>() + first, (size_t)(c - first) * sizeof(fh_face), hipMemcpyDeviceToHost));
         return c;
     });
 }
@@ -297,18 +387,30 @@ int fh_rec_extract(fh_rec* r, const uint8_t* bgr, int rows, int cols, int step, 
     if (!face || !out || step < cols * 3) return arg_error("fh_rec_extract: bad argument");
     if (out_cap < r->rec.dim()) return arg_error("fh_rec_extract: output buffer too small");
     return guarded([&] {
-        const size_t bytes = (size_t)rows * step;
+        const size_t bytes = (size_t)rows * step, used = host_image_bytes(rows, cols, step);
+        const size_t dimb = (size_t)r->rec.dim() * sizeof(float);
         r->img.ensure(bytes);
         r->face.ensure(sizeof(fh_face) + sizeof(int));
-        r->emb.ensure((size_t)r->rec.dim() * sizeof(float));
-        FH_HIP(hipMemcpy(r->img.p, bgr, host_image_bytes(rows, cols, step), hipMemcpyHostToDevice));
-        FH_HIP(hipMemcpy(r->face.p, face, sizeof(fh_face), hipMemcpyHostToDevice));
+        r->emb.ensure(dimb);
+        const bool m1 = r->h_img.ensure(bytes), m2 = r->h_io.ensure(128 + dimb);
+        const bool moved = m1 || m2;
+        if (moved) { r->gcall.reset(); r->gcall_simple.reset(); }
+        char* const io = static_cast<char*>(r->h_io.p);                     // [0,60) face in | [64,68) ok out | [128, ...) embedding out
+        memcpy(r->h_img.p, bgr, used);
+        memcpy(io, face, sizeof(fh_face));
         int* okp = reinterpret_cast<int*>(r->face.as<uint8_t>() + sizeof(fh_face));
-        r->rec.embed_faces_dev(r->img.as<uint8_t>(), rows, cols, step, (long)bytes, r->face.as<fh::FaceRec>(), nullptr, 1, r->emb.as<float>(), okp, nullptr);
-        int ok = 0;
-        FH_HIP(hipMemcpy(&ok, okp, sizeof(int), hipMemcpyDeviceToHost));
-        if (!ok) return 0;                                                 // "Face alignment failed!" :254-257
-        FH_HIP(hipMemcpy(out, r->emb.p, (size_t)r->rec.dim() * sizeof(float), hipMemcpyDeviceToHost));
+        hipStream_t s = r->cs.get();
+        const std::vector<long long> key{rows, cols, step, (long long)(size_t)r->img.p, (long long)(size_t)r->emb.p, (long long)(size_t)r->face.p};
+        r->gcall.run(key, s, [&](hipStream_t st) {
+            FH_HIP(hipMemcpyAsync(r->img.p, r->h_img.p, used, hipMemcpyHostToDevice, st));
+            FH_HIP(hipMemcpyAsync(r->face.p, io, sizeof(fh_face), hipMemcpyHostToDevice, st));
+            r->rec.embed_faces_dev(r->img.as<uint8_t>(), rows, cols, step, (long)bytes, r->face.as<fh::FaceRec>(), nullptr, 1, r->emb.as<float>(), okp, st);
+            FH_HIP(hipMemcpyAsync(io + 64, okp, sizeof(int), hipMemcpyDeviceToHost, st));
+            FH_HIP(hipMemcpyAsync(io + 128, r->emb.p, dimb, hipMemcpyDeviceToHost, st));
+        });
+        FH_HIP(hipStreamSynchronize(s));
+        if (!*reinterpret_cast<int*>(io + 64)) return 0;                    // "Face alignment failed!" :254-257
+        memcpy(out, io + 128, dimb);
         return r->rec.dim();
     });
 }
@@ -319,12 +421,24 @@ int fh_rec_extract_simple(fh_rec* r, const uint8_t* bgr, int rows, int cols, int
     if (!out || step < cols * 3) return arg_error("fh_rec_extract_simple: bad argument");
     if (out_cap < r->rec.dim()) return arg_error("fh_rec_extract_simple: output buffer too small");
     return guarded([&] {
-        const size_t bytes = (size_t)rows * step;
+        const size_t bytes = (size_t)rows * step, used = host_image_bytes(rows, cols, step);
+        const size_t dimb = (size_t)r->rec.dim() * sizeof(float);
         r->img.ensure(bytes);
-        r->emb.ensure((size_t)r->rec.dim() * sizeof(float));
-        FH_HIP(hipMemcpy(r->img.p, bgr, host_image_bytes(rows, cols, step), hipMemcpyHostToDevice));
-        r->rec.resize_embed_dev(r->img.as<uint8_t>(), 1, rows, cols, step, (long)bytes, r->emb.as<float>(), nullptr);
-        FH_HIP(hipMemcpy(out, r->emb.p, (size_t)r->rec.dim() * sizeof(float), hipMemcpyDeviceToHost));
+        r->emb.ensure(dimb);
+        const bool m1 = r->h_img.ensure(bytes), m2 = r->h_io.ensure(128 + dimb);
+        const bool moved = m1 || m2;
+        if (moved) { r->gcall.reset(); r->gcall_simple.reset(); }
+        char* const io = static_cast<char*>(r->h_io.p);
+        memcpy(r->h_img.p, bgr, used);
+        hipStream_t s = r->cs.get();
+        const std::vector<long long> key{rows, cols, step, (long long)(size_t)r->img.p, (long long)(size_t)r->emb.p};
+        r->gcall_simple.run(key, s, [&](hipStream_t st) {
+            FH_HIP(hipMemcpyAsync(r->img.p, r->h_img.p, used, hipMemcpyHostToDevice, st));
+            r->rec.resize_embed_dev(r->img.as<uint8_t>(), 1, rows, cols, step, (long)bytes, r->emb.as<float>(), st);
+            FH_HIP(hipMemcpyAsync(io + 128, r->emb.p, dimb, hipMemcpyDeviceToHost, st));
+        });
+        FH_HIP(hipStreamSynchronize(s));
+        memcpy(out, io + 128, dimb);
         return r->rec.dim();
     });
 }
@@ -661,6 +775,17 @@ int fh_conv_pack_weights(const float* w_ohwi, int cout, int cin, int ksize, floa
     return 0;
 }
 int fh_conv_kpad(int ktot) { return fh::conv_kpad(ktot); }
+int fh_set_graph_replay(int on) { g_graph_replay = on != 0; return FH_OK; }
+int fh_det_graph_stats(fh_det* d, long long* replays) {
+    if (!d) return arg_error("null handle");
+    if (replays) *replays = d->gcall.replays;
+    return (int)d->gcall.nodes;
+}
+int fh_rec_graph_stats(fh_rec* r, long long* replays) {
+    if (!r) return arg_error("null handle");
+    if (replays) *replays = r->gcall.replays + r->gcall_simple.replays;
+    return (int)(r->gcall.nodes ? r->gcall.nodes : r->gcall_simple.nodes);
+}
 int fh_debug_streamk(int drop_publish, int timeout_ms) { fh::conv_debug_streamk(drop_publish, timeout_ms); return 0; }
 int fh_conv_forward_dev(const float* in, const float* wt, const float* bias, float* out, int batch, int h, int w, int cin, int cout,
                         int ks, int stride, int kpad, int cfg, void* stream) {

@@ -241,6 +241,14 @@ FH_API int fh_conv_forward_dev(const float* d_in, const float* d_wt_packed, cons
  * [cout][3*3][cin]; cin % 32 == 0, cout % 4 == 0.  Synchronous. */
 FH_API int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi_host, const float* d_bias, float* d_out, int batch, int h, int w,
                                 int cin, int cout, void* stream);
+/* Batch-1 host-pointer calls (fh_det_detect, fh_rec_extract, fh_rec_extract_simple — the reference's own mode, src/main.cpp:88-104) are
+ * captured into a HIP graph per call shape (image size / pitch, thresholds) and replayed: first call with a shape eager, second
+ * captured, later ones one hipGraphLaunch each.  Results are bitwise those of the eager path.  fh_set_graph_replay(0) (or
+ * FACEHIP_GRAPH=0) turns it off process-wide; fh_*_graph_stats return the node count of the handle's captured graph (0 = none yet)
+ * and the number of replayed calls. */
+FH_API int fh_set_graph_replay(int on);
+FH_API int fh_det_graph_stats(fh_det* d, long long* replays);
+FH_API int fh_rec_graph_stats(fh_rec* r, long long* replays);
 /* Stream-K watchdog test hook (conv_mfma.hip): drop_publish != 0 makes the helper workgroups of a remainder round "lose" their
  * publication, timeout_ms bounds the owners' wait (0 = the 2 s default).  An owner whose wait times out abandons its tile and the
  * next fh_* call returns FH_ERR_DEVICE ("stream-K hand-off timed out ...") instead of the process hanging with the GPU. */

@@ -299,3 +299,51 @@ def test_gallery_rows_need_not_be_unit_vectors():
             np.testing.assert_allclose(gs[a], exact[a, gi[a]], rtol=1e-4, atol=1e-3)
         if gm is not gal:
             assert gs.max() < -1.0
+
+
+def test_batch1_graph_replay_is_bitwise_the_eager_path(models_dir):
+    """The reference's own mode is one image per call (face_detector.cpp:170, face_recognizer.cpp:270; callers main.cpp:88-104).
+    `fh_det_detect` / `fh_rec_extract` / `fh_rec_extract_simple` replay a HIP graph captured per call shape: the third and later calls
+    with one shape are graph replays.  Every call must return exactly what the eager path returns — for fresh image CONTENT on every
+    replay (the graph re-reads the pinned staging buffer), across a threshold change and an image-size change (new capture)."""
+    import ctypes as C
+    L = fa.lib()
+    det = fa.FaceDetector(); rec = fa.FaceRecognizer()
+    assert det.loadModel(util.tiny_scrfd(models_dir, hw=128, cls_bias=-2.0)) and rec.loadModel(util.tiny_iresnet(models_dir))
+    imgs = list(util.frames_u8(6, 128, 128, seed=140, smooth=True)) + list(util.frames_u8(3, 96, 120, seed=141, smooth=True))
+    calls = [(im, 0.5, 0.4) for im in imgs[:6]] + [(imgs[1], 0.3, 0.4), (imgs[2], 0.3, 0.4), (imgs[3], 0.3, 0.4)] + \
+            [(im, 0.5, 0.4) for im in imgs[6:]]
+
+    def run_all():
+        det_out, feat_out, simple_out = [], [], []
+        for im, thr, nms in calls:
+            f = det.detect_records(im, thr, nms)
+            det_out.append(f.copy())
+            if len(f):
+                feat_out.append(rec.extractFeature(im, f[0]).copy())
+            simple_out.append(rec.extractFeatureSimple(im).copy())
+        return det_out, feat_out, simple_out
+
+    try:
+        assert L.fh_set_graph_replay(0) == 0
+        eager = run_all()
+        n = C.c_longlong(0)
+        assert L.fh_det_graph_stats(det.handle, C.byref(n)) == 0 and n.value == 0          # nothing captured in eager mode
+        assert L.fh_set_graph_replay(1) == 0
+        graph = run_all()
+    finally:
+        L.fh_set_graph_replay(1)
+    nodes = L.fh_det_graph_stats(det.handle, C.byref(n))
+    assert nodes > 10 and n.value >= 5, (nodes, n.value)                                  # 12 calls in 3 shapes: >= 5 of them replays / captures
+    rn = C.c_longlong(0)
+    assert L.fh_rec_graph_stats(rec.handle, C.byref(rn)) > 10 and rn.value >= 5
+    assert sum(len(f) for f in eager[0]) > 0
+    for a, b in zip(eager[0], graph[0]):
+        assert a.tobytes() == b.tobytes()
+    assert len(eager[1]) == len(graph[1]) > 0
+    for a, b in zip(eager[1] + eager[2], graph[1] + graph[2]):
+        assert a.shape == (512,) and np.array_equal(a, b)
+    # and still the oracle's answer (one spot check; the eager path is oracle-checked throughout tests/test_gpu_parity.py)
+    orec = oracle.OracleRecognizer(); assert orec.loadModel(util.tiny_iresnet(models_dir))
+    f = det.detect_records(imgs[0], 0.5, 0.4)
+    assert 1.0 - float(np.dot(rec.extractFeature(imgs[0], f[0]), orec.extractFeature(imgs[0], f[0]))) < 1e-5
