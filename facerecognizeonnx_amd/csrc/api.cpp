@@ -775,6 +775,7 @@ int fh_conv_pack_weights(const float* w_ohwi, int cout, int cin, int ksize, floa
     return 0;
 }
 int fh_conv_kpad(int ktot) { return fh::conv_kpad(ktot); }
+const float* fh_det_workspace_dev(fh_det* d) { return d ? d->det.net().workspace() : nullptr; }
 int fh_set_graph_replay(int on) { g_graph_replay = on != 0; return FH_OK; }
 int fh_det_graph_stats(fh_det* d, long long* replays) {
     if (!d) return arg_error("null handle");

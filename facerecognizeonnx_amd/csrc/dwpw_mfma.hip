@@ -374,8 +374,7 @@ __device__ __forceinline__ void front_barrier() {
 template <bool STEP4>
 __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_total) {
     __shared__ unsigned stage[2][FR_ROWS * FR_PITCH];
-    __shared__ v4f halo[192 * 4];
-    __shared__ v4f At[DP_BM * 8];
+    __shared__ v4f halo[192 * 5];                                          // [180 pixels][16 channels], pixel pitch 5 float4 (odd: lane = pixel reads spread over all banks)
     __shared__ v4f Wt[32 * 8];
     __shared__ v4f cst[48];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -389,7 +388,6 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
         const int lrow = tid >> 3, lqs = (tid & 7) ^ ((lrow >> 1) & 7);
         dwpw_dma16(p.wt + (size_t)lrow * p.Kpad + lqs * 4, Wt + wid * 64);
     }
-    const int dq = tid & 3, dp = tid >> 2;                                 // depthwise: 16-byte column dq of pixels dp, dp + 64
     // depthwise weights [9][16], depthwise bias [16], pointwise bias [32] live in LDS (re-read per tile) — in registers they would push
     // the kernel past the 128 VGPRs that 4 workgroups per CU allow
     if (tid < 36) cst[tid] = *reinterpret_cast<const v4f*>(p.dw_w + tid * 4);
@@ -498,7 +496,7 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
                 for (int c = 0; c < 4; ++c) a4[c] = a4[c] > 0.f ? a4[c] : 0.f;
             }
             if (!inmap) a4 = v4f{0.f, 0.f, 0.f, 0.f};                       // outside the map: the depthwise zero padding
-            if (store) halo[hp * 4 + g] = a4;
+            if (store) halo[hp * 5 + g] = a4;
         };
 #pragma unroll
         for (int i = 0; i < NG; ++i) {                                      // (wave-uniform trip count: the MFMAs run with all lanes)
@@ -563,58 +561,333 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
             }
         }
         front_barrier();
-        // 3. depthwise 3x3 (+bias +activation) -> A tile
+        // 3 + 4 merged (round 3, as dwpw_reg_kernel): a wave owns 32 pixels, lane = (pixel fr, half fh2); the depthwise 3x3 of channels
+        // 8 j + 4 fh2 .. + 3 of ITS pixel is the B fragment of the pointwise MFMAs — no A tile, no barrier between the two, and the
+        // 16 KB the A tile took are gone from LDS.  Accumulators start from the pointwise bias.  One MFMA per slot, the next
+        // step's tap reads RA tap-slots ahead (ring registers), pinned by sched_barrier.
         {
-            const int py = dp / DP_TW, pxx = dp - py * DP_TW;               // pixels dp and dp + 64 = four rows further down
-            v4f a0 = cst[36 + dq], a1 = a0;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const v4f w = cst[(ky * 3 + kx) * 4 + dq];
-                    a0 += halo[((py + ky) * DP_HW + pxx + kx) * 4 + dq] * w;
-                    a1 += halo[((py + 4 + ky) * DP_HW + pxx + kx) * 4 + dq] * w;
-                }
-            if (p.dw_act == (int)Act::RELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { a0[e] = a0[e] > 0.f ? a0[e] : 0.f; a1[e] = a1[e] > 0.f ? a1[e] : 0.f; }
-            }
-            At[dp * 8 + (dq ^ ((dp >> 1) & 7))] = a0;
-            At[(dp + 64) * 8 + (dq ^ (((dp + 64) >> 1) & 7))] = a1;
-        }
-        front_barrier();
-        // 4. pointwise: wave = 32 pixels x 32 output channels, K = 16
-        v16f acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-        const v4f* X = At + (wid * 32 + fr) * 8;
-        const v4f* Wp = Wt + fr * 8;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int col = (2 * s2 + fh2) ^ fsw;
-            const v4f x = X[col], w = Wp[col];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e], x[e], acc, 0, 0, 0);
-        }
-        const int r = wid * 32 + fr;
-        const int oy = cty0 + r / DP_TW, ox = ctx0 + r % DP_TW;
-        if (oy < p.Ho && ox < p.Wo) {
-            float* __restrict__ orow = p.out1 + (((size_t)cn * p.Ho + oy) * p.Wo + ox) * p.Cout;
+            const int pr_ = wid * 32 + fr, py = pr_ / DP_TW, pxx = pr_ - py * DP_TW;
+            const v4f* const hb = halo + (py * DP_HW + pxx) * 5 + fh2;
+            const v4f* const db = cst + fh2;                                // [tap][4] + 2 j ; bias at tap 9
+            v16f acc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int co = 4 * fh2 + 8 * q;
-                if (co >= p.Cout) continue;
                 const v4f pb = cst[40 + fh2 + 2 * q];
-                v4f v;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float u = acc[4 * q + c] + pb[c];
-                    if (p.act == (int)Act::RELU) u = u > 0.f ? u : 0.f;
-                    v[c] = u;
+                for (int c = 0; c < 4; ++c) acc[4 * q + c] = pb[c];
+            }
+            constexpr int NT = 10, RA = 4, RING = 5, STEPS = 2;
+            v4f hv[RING], dv[RING];
+            auto issue = [&](int G) __attribute__((always_inline)) {
+                const int jj = G / NT, tt = G % NT;
+                if (jj >= STEPS) return;
+                dv[G % RING] = db[(tt == 0 ? 9 : tt - 1) * 4 + 2 * jj];
+                if (tt > 0) hv[G % RING] = hb[(((tt - 1) / 3) * DP_HW + (tt - 1) % 3) * 5 + 2 * jj];
+            };
+            v4f an;
+            auto consume = [&](int G) __attribute__((always_inline)) {
+                if (G / NT >= STEPS) return;
+                if (G % NT == 0) an = dv[G % RING]; else an += hv[G % RING] * dv[G % RING];
+            };
+            const float dfl = p.dw_act == (int)Act::RELU ? 0.f : -INFINITY, ofl = p.act == (int)Act::RELU ? 0.f : -INFINITY;
+            const v4f* Wp = Wt + fr * 8;
+#pragma unroll
+            for (int G = 0; G < RA; ++G) issue(G);
+#pragma unroll
+            for (int G = 0; G < NT; ++G) { issue(G + RA); consume(G); }
+#pragma unroll
+            for (int j = 0; j < STEPS; ++j) {
+                v4f a;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = fmaxf(an[e], dfl);
+                const v4f w = Wp[(2 * j + fh2) ^ fsw];
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[sl], a[sl], acc, 0, 0, 0);
+#pragma unroll
+                    for (int G = NT * (j + 1) + sl * NT / 4; G < NT * (j + 1) + (sl + 1) * NT / 4; ++G) { issue(G + RA); consume(G); }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                *reinterpret_cast<v4f*>(orow + co) = v;
+            }
+            const int oy = cty0 + py, ox = ctx0 + pxx;
+            if (oy < p.Ho && ox < p.Wo) {
+                float* __restrict__ orow = p.out1 + (((size_t)cn * p.Ho + oy) * p.Wo + ox) * p.Cout;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int co = 4 * fh2 + 8 * q;
+                    if (co >= p.Cout) continue;
+                    v4f v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[4 * q + c], ofl);
+                    *reinterpret_cast<v4f*>(orow + co) = v;
+                }
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Register-fed form of the stride-1 block (round 3): depthwise 3x3 -> pointwise 1x1 with NO A tile in LDS and NO barrier in the K loop.
+//
+// dwpw_kernel above spends its time in its phase chain, not on bandwidth or arithmetic (phase timers, 80x80x72: DMA issue 11 k,
+// depthwise 8.9 k, prologue 9.5 k cycles per tile): per 32-channel chunk every wave waits at two barriers, the depthwise result makes a
+// round trip through LDS, a chunk with few live channels (40 = 32 + 8) idles three quarters of the depthwise lanes, and every tile pays
+// the prologue again.  Here:
+//   * a wave owns 32 pixels of the 8 x 16 tile for the WHOLE K loop: lane = (pixel r = lane & 31, half h = lane >> 5).  For the 8-channel
+//     step j it evaluates the depthwise 3x3 (+bias +ReLU) of channels 8j + 4h .. + 3 of ITS pixel straight from the halo image — a
+//     float4 that is exactly the B fragment v_mfma_f32_32x32x2_f32 wants from that lane (k = 8j + e for h = 0, 8j + 4 + e for h = 1,
+//     e = 0..3): the result goes from the vector ALU into the matrix core without touching LDS.  Waves never wait for each other
+//     inside a tile, so one wave's depthwise FMAs / LDS reads overlap another's MFMAs on the same SIMD.
+//   * the halo holds ALL channels of the tile at once ([180 pixels][C + 4 floats]: pitch 4 * odd, so the 16-byte reads of
+//     neighbouring pixels spread over all banks), the pointwise weights sit in LDS in fragment order for the kernel's lifetime,
+//     depthwise taps + biases too.
+//   * persistent workgroups; the NEXT tile's halo is fetched global -> registers while this tile computes (front_kernel's scheme: no
+//     second halo buffer, so the occupancy stays), written to LDS between two LDS-only barriers.
+//   * the halo comes in through BUFFER loads with a per-image descriptor: rows above / below the image are out of range and read as
+//     zero in hardware, columns left / right of it are pushed out of range by one select (edge tiles only) — no per-item bounds
+//     arithmetic, no branches, and the loads of a tile issue back to back.
+//   * accumulators start from the pointwise bias; the epilogue is ReLU + float4 stores.
+// Phase stamps (scripts/dwpw_prof.sh, 80x80x72 -> 72, cycles per tile and workgroup): barriers 1.4 k, registers -> LDS 0.8 k, prefetch
+// issue 1.8 k, K loop 14.7 k (= two waves per SIMD sharing the matrix pipe at 6.9 k of MFMA issue each: the loop is MFMA-bound; a
+// third of those MFMAs multiply the padding 72 -> 96 columns), stores 2.4 k.
+// Measured and dropped: a straight-line epilogue (template-constant store count, lanes outside the map storing to a sink) so that the
+// compiler's wait for the prefetched registers becomes the exact `vmcnt(stores + later loads)` instead of vmcnt(0): the ISA showed
+// vmcnt(21)..(9) as intended, the layers ran no faster and the 16-channel layers slower.
+// C % 8 == 0 (CQ = C / 4 even), Cout % 4 == 0, Cout <= 32 * TN.
+template <int CQ, int TN, int OCC>
+__global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_total) {
+    static_assert(CQ % 2 == 0, "whole 8-channel MFMA steps");
+    constexpr int C = CQ * 4, STEPS = C / 8;
+    constexpr int PQ = CQ + 1;                                             // halo pixel pitch in float4 (odd)
+    constexpr int NPF = (DP_HALO * CQ + 255) / 256;                        // prefetched float4 per thread
+    extern __shared__ v4f smem[];
+    v4f* const halo = smem;                                                // [180][PQ]
+    v4f* const dwl = halo + DP_HALO * PQ;                                  // [10][CQ]: 9 taps + bias
+    v4f* const Wl = dwl + 10 * CQ;                                         // [STEPS][2][Cout]: A fragments (n = row, 4 k of half h)
+    float* const pwb = reinterpret_cast<float*>(Wl + STEPS * 2 * p.Cout);  // [32 * TN] pointwise bias (zero behind Cout)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int Cout = p.Cout;
+    // ReLU (floor 0) or none (floor -inf) as one v_max: a branch per step would end the basic block and with it the overlap of the steps
+    const float dw_floor = p.dw_act == (int)Act::RELU ? 0.f : -INFINITY, out_floor = p.act == (int)Act::RELU ? 0.f : -INFINITY;
+
+    // ---- once per workgroup
+    for (int i = tid; i < 10 * CQ; i += 256) {
+        const int k = i / CQ, q = i - k * CQ;
+        dwl[i] = *reinterpret_cast<const v4f*>(k < 9 ? p.dw_w + (size_t)k * C + 4 * q : p.dw_b + 4 * q);
+    }
+    for (int i = tid; i < STEPS * 2 * Cout; i += 256) {
+        const int n = i % Cout, jh = i / Cout;                             // jh = 2 j + h
+        Wl[i] = *reinterpret_cast<const v4f*>(p.wt + (size_t)n * p.Kpad + 4 * jh);
+    }
+    for (int i = tid; i < 32 * TN; i += 256) pwb[i] = i < Cout ? p.bias[i] : 0.f;
+
+    // this lane's pixel and fragment addresses (float4 units)
+    const int pix = wid * 32 + r, py = pix / DP_TW, px = pix - py * DP_TW;
+    const v4f* const hbase = halo + (py * DP_HW + px) * PQ + h;            // + (ky * 18 + kx) * PQ + 2 j
+    const v4f* const dbase = dwl + h;                                      // + tap * CQ + 2 j
+    int wrow[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) wrow[jn] = h * Cout + min(32 * jn + r, Cout - 1);   // rows >= Cout: any valid address (their columns are never stored)
+
+    // ---- tiles: XCD x owns a contiguous run, its workgroups walk it side by side
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, wgs = gridDim.x >> 3;       // (gridDim.x is a multiple of 8)
+    const int q8 = tiles_total >> 3, r8 = tiles_total & 7;
+    const int run0 = xcd * q8 + min(xcd, r8), run1 = run0 + q8 + (xcd < r8 ? 1 : 0);
+    const int per_img = tiles_x * tiles_y;
+
+    // halo of tile t: global -> registers (issued, not waited for).  Per thread and item the byte offset relative to the tile's halo
+    // origin is tile-invariant (voff); per tile: one add each, and on tiles that touch the left / right border a select.
+    v4f pf[NPF];
+    int voff[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+        const int i = min(tid + 256 * k, DP_HALO * CQ - 1);
+        const int hp = i / CQ, q = i - hp * CQ;
+        const int hy = hp / DP_HW, hx = hp - hy * DP_HW;
+        voff[k] = ((hy * p.W + hx) * C + 4 * q) * 4;
+    }
+    const int img_bytes = p.H * p.W * C * 4;
+    auto prefetch = [&](int t) __attribute__((always_inline)) {
+        const int n = t / per_img, rem = t - n * per_img;
+        const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+        const int y0 = tyi * DP_TH - 1, x0 = txi * DP_TW - 1;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + (size_t)n * p.H * p.W * C), 0, img_bytes, 0x00020000);
+        const int tile_off = (y0 * p.W + x0) * C * 4;                       // (negative on the first tile row / column: wraps out of range)
+        int vo[NPF];
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) vo[k] = tile_off + voff[k];
+        if (x0 < 0 || x0 + DP_HW > p.W) {                                   // wave-uniform: only the first / last tile column
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const int i = min(tid + 256 * k, DP_HALO * CQ - 1);
+                const int hx = (i / CQ) % DP_HW;
+                vo[k] = (unsigned)(x0 + hx) < (unsigned)p.W ? vo[k] : (int)0x80000000;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) pf[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo[k], 0, 0));
+    };
+    int t = run0 + wg;
+    if (t < run1) prefetch(t);
+    front_barrier();                                                        // dwl / Wl / pwb written by all waves
+#ifdef FACEHIP_DWPW_PROF
+    long long ph[6] = {0, 0, 0, 0, 0, 0}; long long st0; int ntiles = 0;
+#define DWPW_STAMP(i) { const long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - st0; st0 = now_; }
+#else
+#define DWPW_STAMP(i)
+#endif
+    for (; t < run1; t += wgs) {
+        const int n = t / per_img, rem = t - n * per_img;
+        const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+        const int ty0 = tyi * DP_TH, tx0 = txi * DP_TW;
+#ifdef FACEHIP_DWPW_PROF
+        st0 = __builtin_readcyclecounter(); ++ntiles;
+#endif
+        front_barrier();                                                    // every wave is done reading the previous tile's halo
+        DWPW_STAMP(0)
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + 256 * k;
+            if (i < DP_HALO * CQ) halo[i + i / CQ] = pf[k];              // pixel pitch PQ = CQ + 1
+        }
+        DWPW_STAMP(1)
+        if (t + wgs < run1) prefetch(t + wgs);
+        DWPW_STAMP(2)
+        front_barrier();                                                    // halo complete
+        DWPW_STAMP(3)
+
+        v16f acc[TN];
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4f b = *reinterpret_cast<const v4f*>(pwb + 32 * jn + 8 * g + 4 * h);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[jn][4 * g + c] = b[c];
+            }
+        // ---- K loop, hand-scheduled.  Left to itself the compiler emits, per step, nine times (2 ds_read, wait, 2 FMA) and only then the
+        // step's MFMAs (ds_read, wait, 4 MFMA): every LDS latency exposed, nothing beside the matrix pipe.  So the order is written
+        // out: one MFMA per SLOT; behind it the slot's share of the NEXT step's depthwise — each tap's two LDS reads are issued RA
+        // tap-slots ahead of their FMAs (ring registers hv / dv), the next 32-column group's weight fragment four slots ahead — and a
+        // sched_barrier(0) pins the slot.  The counted lgkmcnt waits the compiler inserts are then exact (LDS returns in order).
+        constexpr int NS = 4 * TN;                                          // MFMA slots per 8-channel step
+        constexpr int NT = 10;                                              // tap-slots per step: the depthwise bias, then the 9 taps
+        constexpr int RA = 4, RING = 5;
+        v4f hv[RING], dv[RING], wq[2];
+        auto issue = [&](int G) __attribute__((always_inline)) {           // LDS reads of global tap-slot G = NT * step + t
+            const int jj = G / NT, tt = G % NT;
+            if (jj >= STEPS) return;
+            dv[G % RING] = dbase[(tt == 0 ? 9 : tt - 1) * CQ + 2 * jj];
+            if (tt > 0) hv[G % RING] = hbase[(((tt - 1) / 3) * DP_HW + (tt - 1) % 3) * PQ + 2 * jj];
+        };
+        v4f an;
+        auto consume = [&](int G) __attribute__((always_inline)) {
+            if (G / NT >= STEPS) return;
+            if (G % NT == 0) an = dv[G % RING]; else an += hv[G % RING] * dv[G % RING];
+        };
+        auto wfrag = [&](int grp) __attribute__((always_inline)) {         // A fragment of (step grp / TN, column group grp % TN)
+            if (grp < STEPS * TN) wq[grp & 1] = Wl[2 * (grp / TN) * Cout + wrow[grp % TN]];
+        };
+        wfrag(0);
+#pragma unroll
+        for (int G = 0; G < RA; ++G) issue(G);
+#pragma unroll
+        for (int G = 0; G < NT; ++G) { issue(G + RA); consume(G); }         // step 0's depthwise: nothing to hide behind yet
+        v4f a;
+#pragma unroll
+        for (int j = 0; j < STEPS; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] = fmaxf(an[e], dw_floor);
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const int grp = j * TN + sl / 4;
+                if (sl % 4 == 0) wfrag(grp + 1);
+                acc[sl / 4] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[grp & 1][sl % 4], a[sl % 4], acc[sl / 4], 0, 0, 0);
+#pragma unroll
+                for (int G = NT * (j + 1) + sl * NT / NS; G < NT * (j + 1) + (sl + 1) * NT / NS; ++G) { issue(G + RA); consume(G); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        DWPW_STAMP(4)
+        // ---- epilogue: lane = pixel, accumulator quads = 4 consecutive channels
+        const int oy = ty0 + py, ox = tx0 + px;
+        if (oy < p.Ho && ox < p.Wo) {
+            float* __restrict__ orow = p.out1 + (((size_t)n * p.Ho + oy) * p.Wo + ox) * Cout;
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = 32 * jn + 8 * g + 4 * h;
+                    if (co >= Cout) continue;
+                    v4f v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[jn][4 * g + c], out_floor);
+                    *reinterpret_cast<v4f*>(orow + co) = v;
+                }
+        }
+        DWPW_STAMP(5)
+    }
+#ifdef FACEHIP_DWPW_PROF
+    if (lane == 0 && p.slabs) {                                             // [workgroup][wave][8]: 6 phase sums, tile count
+        long long* o = reinterpret_cast<long long*>(p.slabs) + ((size_t)blockIdx.x * 4 + wid) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = ph[i];
+        o[6] = ntiles;
+    }
+#endif
+}
+
+// Measured and not kept (round 3): the register-fed form WITHOUT a halo image for the stride-2 blocks (every lane gathers the nine taps of
+// its own pixel straight from memory into the ring registers, no barrier in the tile loop at all): 496 / 369 us against 322 / 255 us
+// of dwpw_kernel<.., 2, .., true> on 320x320x16 -> 160x160x40 / 160x160x40 -> 80x80x72.  With lane = pixel a wave-instruction touches 64
+// different 128-byte lines (16 bytes each, stride 2 pixels): the loads are bound by tag look-ups, not by bytes.  The strip form of
+// dwpw_kernel (lane = 16-byte channel column, 4 lanes per 64-byte pixel) keeps them coalesced and stays.
+
+static size_t dwpw_reg_lds(int CQ, int Cout, int TN) {
+    return ((size_t)DP_HALO * (CQ + 1) + 10 * CQ + (size_t)(CQ / 2) * 2 * Cout) * 16 + (size_t)32 * TN * 4;
+}
+static bool dwpw_reg_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FACEHIP_DWPW_REG"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+template <int CQ, int TN, int OCC>
+static void launch_dwpw_reg_cfg(const ConvArgs& a, hipStream_t s) {
+    const int tiles_x = (a.Wo + DP_TW - 1) / DP_TW, tiles_y = (a.Ho + DP_TH - 1) / DP_TH;
+    const int tiles_total = a.B * tiles_y * tiles_x;
+    const int cus = a.cus > 0 ? a.cus : conv_num_cus();
+    const size_t lds = dwpw_reg_lds(CQ, a.Cout, TN);
+    static bool attr_set = false;                                          // (per instantiation) dynamic LDS beyond the 64 KB default needs the opt-in
+    if (!attr_set) {
+        FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpw_reg_kernel<CQ, TN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int grid = std::min((tiles_total + 7) / 8 * 8, cus * OCC);
+    grid = std::max(8, grid / 8 * 8);
+    hipLaunchKernelGGL((dwpw_reg_kernel<CQ, TN, OCC>), dim3((unsigned)grid), dim3(256), lds, s, a, tiles_x, tiles_y, tiles_total);
+}
+// true = launched.  Instantiated for SCRFD-500M's stride-1 blocks (C = 16 / 40 / 64 / 72) with any Cout <= 96.
+static bool launch_dwpw_reg(const ConvArgs& a, hipStream_t s) {
+    if (!dwpw_reg_enabled() || a.dw_stride != 1 || a.u8_src || a.Cout % 4 || a.Cout > 96 || a.H != a.Ho || a.W != a.Wo) return false;
+    if (a.act != (int)Act::NONE && a.act != (int)Act::RELU) return false;
+    if ((long)a.H * a.W * a.Cin * 4 >= (1L << 31)) return false;            // one image must fit a 32-bit buffer range
+    const int tn = (a.Cout + 31) / 32;
+    switch (a.Cin) {
+        case 16:
+            if (tn == 1) launch_dwpw_reg_cfg<4, 1, 4>(a, s); else if (tn == 2) launch_dwpw_reg_cfg<4, 2, 4>(a, s); else launch_dwpw_reg_cfg<4, 3, 3>(a, s);
+            return true;
+        case 40:
+            if (tn == 1) launch_dwpw_reg_cfg<10, 1, 3>(a, s); else if (tn == 2) launch_dwpw_reg_cfg<10, 2, 3>(a, s); else launch_dwpw_reg_cfg<10, 3, 3>(a, s);
+            return true;
+        case 64:
+            if (tn == 1) launch_dwpw_reg_cfg<16, 1, 2>(a, s); else if (tn == 2) launch_dwpw_reg_cfg<16, 2, 2>(a, s); else launch_dwpw_reg_cfg<16, 3, 2>(a, s);
+            return true;
+        case 72:
+            if (tn == 1) launch_dwpw_reg_cfg<18, 1, 2>(a, s); else if (tn == 2) launch_dwpw_reg_cfg<18, 2, 2>(a, s); else launch_dwpw_reg_cfg<18, 3, 2>(a, s);
+            return true;
+        default: return false;
     }
 }
 
@@ -640,6 +913,7 @@ void launch_dwpw(const ConvArgs& a0, hipStream_t s) {
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
     if (a.u8_src) launch_front(a, s);
+    else if (launch_dwpw_reg(a, s)) {}
     else if (a.Cout <= 32) launch_dwpw_cfg<32, 4, 1>(a, s);
     else if (a.Cout <= 64) launch_dwpw_cfg<64, 2, 2>(a, s);
     else if (a.Cout <= 96) launch_dwpw_cfg<96, 4, 1>(a, s);

@@ -476,6 +476,7 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 a.B = batch; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
                 a.ks = 1; a.stride = 1; a.pad = 0; a.Kpad = d.Kpad; a.act = (int)op.act;
                 a.t_flops = 2.0 * op.macs * batch; a.t_bytes = op.bytes * batch;
+                a.slabs = partial_.as<float>();                             // (diagnostic builds park their phase stamps there)
                 launch_dwpw(a, s);
                 break;
             }

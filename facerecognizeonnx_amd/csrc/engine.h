@@ -84,6 +84,9 @@ class Net {
         bool fuse_keep_out1 = true;                           //   something else reads the plain output too (e.g. a later residual): write it
         int Kpad = 0;
     };
+  public:
+    float* workspace() const { return partial_.as<float>(); }   // stream-K slabs (diagnostic builds of dwpw_mfma.hip park phase stamps there)
+  private:
     float* tensor_ptr(int t) const { return arena_.as<float>() + plan_.tensors[t].offset * (size_t)cap_; }
     Plan plan_;
     std::vector<DevOp> dev_;

@@ -247,6 +247,7 @@ FH_API int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi_host, con
  * FACEHIP_GRAPH=0) turns it off process-wide; fh_*_graph_stats return the node count of the handle's captured graph (0 = none yet)
  * and the number of replayed calls. */
 FH_API int fh_set_graph_replay(int on);
+FH_API const float* fh_det_workspace_dev(fh_det* d);          /* tuning hook: the detector's stream-K workspace (diagnostic kernel builds write phase stamps there) */
 FH_API int fh_det_graph_stats(fh_det* d, long long* replays);
 FH_API int fh_rec_graph_stats(fh_rec* r, long long* replays);
 /* Stream-K watchdog test hook (conv_mfma.hip): drop_publish != 0 makes the helper workgroups of a remainder round "lose" their

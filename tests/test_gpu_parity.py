@@ -87,6 +87,10 @@ DWPW_CASES = [
     (44, 60, 72, 96, 1),
     (40, 44, 36, 100, 1),
     (56, 40, 100, 24, 1),
+    (50, 70, 64, 64, 1),          # the register-fed stride-1 form (dwpw_reg_kernel): C = 16 / 40 / 64 / 72, ragged tiles in x and y
+    (40, 40, 16, 64, 1),
+    (45, 41, 72, 72, 1),
+    (37, 90, 40, 24, 1),
     (160, 160, 16, 40, 2),
     (163, 175, 40, 72, 2),
     (161, 166, 20, 100, 2),
