@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
 #pragma unroll
                 for (int c = 0; c < 4; ++c) acc[4 * q + c] = pb[c];
             }
-            constexpr int NT = 10, RA = 4, RING = 5, STEPS = 2;
+            constexpr int NT = 10, RA = 2, RING = 3, STEPS = 2;            // (a deeper ring spills: the kernel lives within 128 VGPRs for 4 workgroups per CU)
             v4f hv[RING], dv[RING];
             auto issue = [&](int G) __attribute__((always_inline)) {
                 const int jj = G / NT, tt = G % NT;
