@@ -683,7 +683,7 @@ void Gallery::topk_dev(const float* q, int Q, int k, float* out_score, int* out_
     if (qrows > Q) FH_HIP(hipMemsetAsync(qpack_.as<float>() + (size_t)Q * dim_, 0, (size_t)(qrows - Q) * dim_ * sizeof(float), s));
     FH_HIP(hipMemcpyAsync(qpack_.p, q, (size_t)Q * dim_ * sizeof(float), hipMemcpyDeviceToDevice, s));
     int tpp = 0;
-    const int parts = n_ > 0 ? gallery_parts(n_, Q, &tpp) : 0;
+    const int parts = n_ > 0 ? gallery_parts(n_, Q, dim_, &tpp) : 0;
     ps_.ensure((size_t)std::max(parts, 1) * Q * k * sizeof(float));
     pi_.ensure((size_t)std::max(parts, 1) * Q * k * sizeof(int));
     // ONE pass over the gallery: dot products stay in the MFMA accumulators, per-workgroup top-k lists come out (gallery.hip)

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "kernels.h"
@@ -240,11 +241,211 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 3: the scan with the QUERIES RESIDENT IN LDS.  gallery_topk_kernel above re-loads the 64-query tile for every 128 gallery rows
+// (16 KB per 64-deep chunk through registers and ds_write, two barriers per chunk): for every 256 KB of gallery it moves 128 KB of
+// queries from L2 and synchronises its four waves sixteen times.  At dim <= 512 the whole query tile fits LDS once (64 x 512 x 4 B =
+// 128 KB of the CU's 160): ONE workgroup of 8 waves per CU keeps it there for the kernel's lifetime, [64 rows][dim / 4 float4] with the
+// 16-byte column XOR-swizzled by (row & 15) so that the B-fragment reads of 16 neighbouring rows spread over all banks.  Each wave
+// streams ITS OWN 32 gallery rows straight into registers (one 64-deep chunk = 8 loads = 32 VGPRs ahead of the one being multiplied,
+// the next tile's first chunk issued before the top-k epilogue) and multiplies them with fragments read from the resident image: no
+// barrier and no query traffic inside a tile's K loop.  Per 256-row tile: two LDS-only barriers around the list update.
+//   * top-k as before (admission threshold per query in LDS, candidates appended to a 32-slot queue per query, replay in four rounds on
+//     overflow), but the sorted lists are spread over the waves: query q lives in lane q & 7 of wave q >> 3 — eight insertions per
+//     wave instead of sixty-four in wave 0.
+constexpr int GS_WAVES = 8, GS_BM = GS_WAVES * 32;
+
+__device__ __forceinline__ void gal_barrier() {               // orders LDS traffic only (does not drain vmcnt: the row prefetch stays in flight)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+__global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const GalArgs p) {
+    constexpr int BN = GAL_BN, TN = BN / 32;
+    extern __shared__ v4f gsm[];
+    const int K = p.dim, K4 = K >> 2, chunks = K / 64, k = p.k;
+    v4f* const Ql = gsm;                                                   // [64][K4], column ^ (row & 15)
+    float* const tau_s = reinterpret_cast<float*>(Ql + BN * K4);
+    int* const tau_i = reinterpret_cast<int*>(tau_s + BN);
+    float* const que_s = reinterpret_cast<float*>(tau_i + BN);             // [64][32]
+    int* const que_i = reinterpret_cast<int*>(que_s + BN * GAL_QCAP);
+    int* const cnt = que_i + BN * GAL_QCAP;
+    int* const overflow = cnt + BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh2 = lane >> 5;
+    int t;
+    {
+        const int nb = gridDim.x, qq = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+        t = x * qq + min(x, r8) + (int)(blockIdx.x >> 3);
+    }
+    const int tile_n = t % p.tiles_n, part = t / p.tiles_n;
+    const int n0 = tile_n * BN;
+    const int rt0 = part * p.tiles_per_part, rt1 = min(p.row_tiles, rt0 + p.tiles_per_part);
+    const int myq = lane < 8 ? wid * 8 + lane : -1;                        // the query whose sorted list this thread keeps
+
+    float ls[GAL_KMAX];
+    int li[GAL_KMAX];
+#pragma unroll
+    for (int i = 0; i < GAL_KMAX; ++i) { ls[i] = -INFINITY; li[i] = INT_MAX; }
+    for (int i = tid; i < BN * K4; i += GS_WAVES * 64) {
+        const int q = i / K4, c = i - q * K4;
+        Ql[q * K4 + (c ^ (q & 15))] = *reinterpret_cast<const v4f*>(p.q + (size_t)(n0 + q) * K + 4 * c);
+    }
+    if (tid < BN) {
+        float ts = -INFINITY; int ti = INT_MAX;
+        if (p.seed_i && n0 + tid < p.Q) {
+            const size_t o = (size_t)(n0 + tid) * k + (k - 1);
+            if (p.seed_i[o] >= 0) { ts = p.seed_s[o]; ti = p.seed_i[o]; }
+        }
+        cnt[tid] = 0; tau_s[tid] = ts; tau_i[tid] = ti;
+    }
+    if (tid == 0) *overflow = 0;
+    __syncthreads();
+
+    const v4f* const qrow = Ql + fr * K4;                                  // + j * 32 * K4 + (col ^ swz)
+    const int swz = fr & 15;                                               // (rows fr and fr + 32 share it)
+    v4f xa[2][8];
+    const float* a_ptr = p.zeros;
+    int a_step = 0;
+    auto row_setup = [&](int rt) __attribute__((always_inline)) {
+        const long myrow = (long)rt * GS_BM + wid * 32 + fr;
+        const bool live = myrow < p.G;
+        a_ptr = (live ? p.gal + (size_t)myrow * K : p.zeros) + fh2 * 4;     // dead rows read the zero line (and are masked in the epilogue)
+        a_step = live ? 64 : 0;
+    };
+    auto load_a = [&](v4f (&x)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) x[s] = *reinterpret_cast<const v4f*>(a_ptr + s * 8);
+        a_ptr += a_step;
+    };
+    if (rt0 < rt1) { row_setup(rt0); load_a(xa[0]); }
+    for (int rt = rt0; rt < rt1; ++rt) {
+        const long m0 = (long)rt * GS_BM;
+        v16f acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        auto multiply = [&](const v4f (&x)[8], int kc) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int col = (kc * 16 + 2 * s + fh2) ^ swz;
+                v4f w[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) w[j] = qrow[j * 32 * K4 + col];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s][e], w[j][e], acc[j], 0, 0, 0);
+            }
+        };
+        int kc = 0;
+        for (; kc + 2 <= chunks; kc += 2) {
+            load_a(xa[1]);
+            __builtin_amdgcn_sched_barrier(0);                              // the row loads stay ABOVE the multiply (two register sets in flight)
+            multiply(xa[0], kc);
+            if (kc + 2 < chunks) load_a(xa[0]);
+            else if (rt + 1 < rt1) { row_setup(rt + 1); load_a(xa[0]); }    // the next tile's first chunk flies through the epilogue
+            __builtin_amdgcn_sched_barrier(0);
+            multiply(xa[1], kc + 1);
+        }
+        if (kc < chunks) {                                                  // odd number of 64-deep chunks
+            multiply(xa[0], kc);
+            if (rt + 1 < rt1) { row_setup(rt + 1); load_a(xa[0]); }
+        }
+        // ---- top-k epilogue
+        const long rbase = m0 + wid * 32 + 4 * fh2;
+        auto push = [&](int g_lo, int g_hi) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int qi = j * 32 + fr;
+                const float ts = tau_s[qi];
+                const int ti = tau_i[qi];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if ((e >> 2) < g_lo || (e >> 2) >= g_hi) continue;
+                    const long row = rbase + 8 * (e >> 2) + (e & 3);
+                    const float sc = (acc[j][e] + 1.0f) / 2.0f;
+                    const int gi = (int)(p.idx_base + row);
+                    if (row < p.G && !gal_better(ts, ti, sc, gi)) {
+                        const int slot = atomicAdd(&cnt[qi], 1);
+                        if (slot < GAL_QCAP) { que_s[qi * GAL_QCAP + slot] = sc; que_i[qi * GAL_QCAP + slot] = gi; }
+                        else *overflow = 1;
+                    }
+                }
+            }
+        };
+        auto insert = [&]() {
+            if (myq >= 0) {
+                const int n = min(cnt[myq], GAL_QCAP);
+                for (int c = 0; c < n; ++c) {
+                    float s = que_s[myq * GAL_QCAP + c];
+                    int gi = que_i[myq * GAL_QCAP + c];
+#pragma unroll
+                    for (int pos = 0; pos < GAL_KMAX; ++pos) {
+                        const bool sw = gal_better(s, gi, ls[pos], li[pos]);
+                        const float os = ls[pos]; const int oi = li[pos];
+                        ls[pos] = sw ? s : os; li[pos] = sw ? gi : oi;
+                        s = sw ? os : s; gi = sw ? oi : gi;
+                    }
+                }
+                if (n > 0) {
+                    int km1 = k - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" : "+v"(km1));
+#endif
+                    float ts = ls[0]; int ti = li[0];
+#pragma unroll
+                    for (int pos = 1; pos < GAL_KMAX; ++pos) { ts = pos == km1 ? ls[pos] : ts; ti = pos == km1 ? li[pos] : ti; }
+                    if (ti != INT_MAX && gal_better(ts, ti, tau_s[myq], tau_i[myq])) { tau_s[myq] = ts; tau_i[myq] = ti; }
+                }
+                cnt[myq] = 0;
+            }
+        };
+        push(0, 4);
+        gal_barrier();
+        if (*overflow) {                                                    // (workgroup-uniform: read after the barrier)
+            gal_barrier();
+            if (tid < BN) cnt[tid] = 0;
+            if (tid == 0) *overflow = 0;
+            gal_barrier();
+            for (int g = 0; g < 4; ++g) {
+                push(g, g + 1);
+                gal_barrier();
+                insert();
+                gal_barrier();
+            }
+        } else {
+            insert();
+            gal_barrier();                                                  // lists / thresholds / counters settled before the next tile's pushes
+        }
+    }
+    if (myq >= 0 && n0 + myq < p.Q) {
+        const size_t o = ((size_t)part * p.Q + n0 + myq) * k;
+#pragma unroll
+        for (int pos = 0; pos < GAL_KMAX; ++pos)
+            if (pos < k) { p.ps[o + pos] = li[pos] == INT_MAX ? -1.0f : ls[pos]; p.pi[o + pos] = li[pos] == INT_MAX ? -1 : li[pos]; }
+    }
+}
+
+static bool gallery_scan_ok(int dim) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FACEHIP_GALLERY_SCAN"); on = e ? atoi(e) : 1; }   // (0 = the round-2 kernel: A / B timing)
+    return on && dim <= 512;
+}
+static size_t gallery_scan_lds(int dim) { return (size_t)GAL_BN * (dim / 4) * 16 + (size_t)GAL_BN * (8 + GAL_QCAP * 8 + 4) + 64; }
+
 // parts the row range is cut into for a gallery of G rows and a query batch of Q (the caller sizes its partial-list buffers with it)
-int gallery_parts(long G, int Q, int* tiles_per_part) {
+int gallery_parts(long G, int Q, int dim, int* tiles_per_part) {
+    const bool scan = gallery_scan_ok(dim);
     const int tiles_n = (Q + GAL_BN - 1) / GAL_BN;
-    const long row_tiles = (G + GAL_BM - 1) / GAL_BM;
-    const int slots = conv_num_cus() * 2;                       // 2 resident workgroups per CU (3 measured: no faster, and 768 lists per query leave the merge its slow path)
+    const long bm = scan ? GS_BM : GAL_BM;
+    const long row_tiles = (G + bm - 1) / bm;
+    // resident workgroups: one 8-wave workgroup per CU (queries resident in LDS), or 2 per CU for the round-2 kernel (3 measured: no
+    // faster, and 768 lists per query leave the merge its slow path)
+    const int slots = conv_num_cus() * (scan ? 1 : 2);
     long parts = slots / tiles_n;
     if (parts < 1) parts = 1;
     if (parts > row_tiles) parts = row_tiles;
@@ -266,18 +467,32 @@ void launch_gallery_topk(const float* gal, long G, int dim, const float* qpacked
     a.tiles_n = (Q + GAL_BN - 1) / GAL_BN;
     a.ps = part_score; a.pi = part_idx;
     constexpr long GAL_SEED_ROWS = 4096;
+    const bool scan = gallery_scan_ok(dim);
+    const long bm = scan ? GS_BM : GAL_BM;
+    const size_t lds = scan ? gallery_scan_lds(dim) : 0;
+    if (scan) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gallery_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+    }
+    auto launch = [&](int parts) {
+        if (scan) hipLaunchKernelGGL(gallery_scan_kernel, dim3((unsigned)(parts * a.tiles_n)), dim3(GS_WAVES * 64), lds, s, a);
+        else hipLaunchKernelGGL(gallery_topk_kernel, dim3((unsigned)(parts * a.tiles_n)), dim3(256), 0, s, a);
+    };
     if (G >= 16 * GAL_SEED_ROWS && seed_score && seed_idx) {
         a.G = GAL_SEED_ROWS;
-        a.row_tiles = (int)(GAL_SEED_ROWS / GAL_BM);
-        const int sp = gallery_parts(a.G, Q, &a.tiles_per_part);
-        hipLaunchKernelGGL(gallery_topk_kernel, dim3((unsigned)(sp * a.tiles_n)), dim3(256), 0, s, a);
+        a.row_tiles = (int)(GAL_SEED_ROWS / bm);
+        const int sp = gallery_parts(a.G, Q, dim, &a.tiles_per_part);
+        launch(sp);
         launch_topk_merge(part_score, part_idx, sp, Q, k, seed_score, seed_idx, s);
         a.seed_s = seed_score; a.seed_i = seed_idx;
     }
     a.G = G;
-    a.row_tiles = (int)((G + GAL_BM - 1) / GAL_BM);
-    const int parts = gallery_parts(G, Q, &a.tiles_per_part);
-    hipLaunchKernelGGL(gallery_topk_kernel, dim3((unsigned)(parts * a.tiles_n)), dim3(256), 0, s, a);
+    a.row_tiles = (int)((G + bm - 1) / bm);
+    const int parts = gallery_parts(G, Q, dim, &a.tiles_per_part);
+    launch(parts);
 }
 
 }  // namespace fh
