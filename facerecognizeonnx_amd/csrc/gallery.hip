@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
 // the next tile's first chunk issued before the top-k epilogue) and multiplies them with fragments read from the resident image: no
 // barrier and no query traffic inside a tile's K loop.  Per 256-row tile: two LDS-only barriers around the list update.
 //   * top-k as before (admission threshold per query in LDS, candidates appended to a 32-slot queue per query, replay in four rounds on
-//     overflow), but the sorted lists are spread over the waves: query q lives in lane q & 7 of wave q >> 3 — eight insertions per
+//     overflow — eight rounds of 32 rows here), but the sorted lists are spread over the waves: query q lives in lane q & 7 of wave q >> 3 — eight insertions per
 //     wave instead of sixty-four in wave 0.
 constexpr int GS_WAVES = 8, GS_BM = GS_WAVES * 32;
 
@@ -328,19 +328,30 @@ __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const Ga
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        // The query fragments of 8-deep step s + 1 are read at the START of step s (two register sets, pinned with sched_barrier): left to
+        // the compiler they are issued one MFMA before their use — ~100 cycles of cover for an LDS read that takes longer under eight
+        // waves' traffic, and both waves of a SIMD run the same code in step, so they wait together and the matrix pipe idles (PMC,
+        // round 3: 52 % busy).  wq[(8 kc + s) & 1] holds step s of chunk kc; the first step of a tile is read before its loop.
+        v4f wq[2][TN];
+        auto qfrag = [&](int gs) __attribute__((always_inline)) {          // global step index gs = 8 * chunk + s
+            const int col = (2 * gs + fh2) ^ swz;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wq[gs & 1][j] = qrow[j * 32 * K4 + col];
+        };
         auto multiply = [&](const v4f (&x)[8], int kc) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const int col = (kc * 16 + 2 * s + fh2) ^ swz;
-                v4f w[TN];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) w[j] = qrow[j * 32 * K4 + col];
+                const int gs = kc * 8 + s;
+                if (gs + 1 < chunks * 8) qfrag(gs + 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s][e], w[j][e], acc[j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s][e], wq[gs & 1][j][e], acc[j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
+        qfrag(0);
         int kc = 0;
         for (; kc + 2 <= chunks; kc += 2) {
             load_a(xa[1]);
@@ -411,8 +422,8 @@ __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const Ga
             if (tid < BN) cnt[tid] = 0;
             if (tid == 0) *overflow = 0;
             gal_barrier();
-            for (int g = 0; g < 4; ++g) {
-                push(g, g + 1);
+            for (int g = 0; g < 8; ++g) {                                   // eight rounds of 32 rows (4 waves x 8 rows): a queue holds 32
+                if ((wid >> 2) == (g & 1)) push(g >> 1, (g >> 1) + 1);
                 gal_barrier();
                 insert();
                 gal_barrier();
