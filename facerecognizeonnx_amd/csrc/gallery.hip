@@ -19,6 +19,7 @@
 // Bounds: HBM scan (G x dim x 4 bytes once) against 2*Q*G*dim FLOP on the f32 matrix cores — at Q = 64 the two meet.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 #include <cstdlib>
 #include <stdexcept>
@@ -50,6 +51,7 @@ struct GalArgs {
     int* pi;
     const float* seed_s;    // optional [Q][k]: exact top-k of a PREFIX of the gallery — its k-th entry is a valid admission threshold for
     const int* seed_i;      // the whole scan (k rows at least as good exist), so the per-workgroup lists start almost closed
+    int dbg;                // tuning only (FACEHIP_GAL_DBG): 1 = no top-k epilogue, 2 = no MFMAs, 4 = no row loads
 };
 
 __device__ __forceinline__ bool gal_better(float s1, int i1, float s2, int i2) { return s1 > s2 || (s1 == s2 && i1 < i2); }
@@ -242,36 +244,36 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Round 3: the scan with the QUERIES RESIDENT IN LDS.  gallery_topk_kernel above re-loads the 64-query tile for every 128 gallery rows
-// (16 KB per 64-deep chunk through registers and ds_write, two barriers per chunk): for every 256 KB of gallery it moves 128 KB of
-// queries from L2 and synchronises its four waves sixteen times.  At dim <= 512 the whole query tile fits LDS once (64 x 512 x 4 B =
-// 128 KB of the CU's 160): ONE workgroup of 8 waves per CU keeps it there for the kernel's lifetime, [64 rows][dim / 4 float4] with the
-// 16-byte column XOR-swizzled by (row & 15) so that the B-fragment reads of 16 neighbouring rows spread over all banks.  Each wave
-// streams ITS OWN 32 gallery rows straight into registers (one 64-deep chunk = 8 loads = 32 VGPRs ahead of the one being multiplied,
-// the next tile's first chunk issued before the top-k epilogue) and multiplies them with fragments read from the resident image: no
-// barrier and no query traffic inside a tile's K loop.  Per 256-row tile: two LDS-only barriers around the list update.
-//   * top-k as before (admission threshold per query in LDS, candidates appended to a 32-slot queue per query, replay in four rounds on
-//     overflow — eight rounds of 32 rows here), but the sorted lists are spread over the waves: query q lives in lane q & 7 of wave q >> 3 — eight insertions per
-//     wave instead of sixty-four in wave 0.
+// Round 3: the scan with the QUERIES RESIDENT IN LDS and NO barrier between the prologue and the final list merge.
+//
+// gallery_topk_kernel above re-loads the 64-query tile for every 128 gallery rows (16 KB per 64-deep chunk through registers and
+// ds_write, two barriers per chunk), runs its top-k update behind two more barriers per tile, and needs a seed pass (a launch of its
+// own over the first 4 096 rows + a merge) to start with closed lists.  Measured on this kernel's first form (queries resident, but the
+// old epilogue): the seed launch 196 us and the per-tile barriers ~240 us of a 0.86 ms call — with one 8-wave workgroup per CU a
+// barrier stalls the whole CU on its slowest wave's memory latency.  Now:
+//   * queries: at dim <= 512 the whole tile fits LDS once (64 x 512 x 4 B = 128 KB of the CU's 160): [64 rows][dim / 4 float4], 16-byte
+//     column XOR-swizzled by (row & 15) so that the B-fragment reads of 16 neighbouring rows spread over all banks; read as fragments
+//     one 8-deep step AHEAD of their MFMAs (two register sets, sched_barrier).
+//   * gallery rows: each wave streams ITS OWN 32 rows straight into registers, one 64-deep chunk (8 loads, 32 VGPRs) ahead of the one
+//     being multiplied, the next tile's first chunk issued before the epilogue.
+//   * top-k WITHOUT synchronisation: every wave keeps its own sorted list per query, lane l = query l (64 lanes, 64 queries).  The 32x32
+//     accumulator of query block j gives lane (fr, h) the scores of query 32 j + fr on ITS 16 rows; lane l's own query is 32 h + fr, so
+//     per accumulator position one lane^32 exchange (ds_bpermute, no LDS memory) hands every lane the partner's score for its query.
+//     A candidate is inserted by one compare-exchange pass over the 16 register slots.  Admission threshold: one float per query in
+//     LDS, raised by any wave to the k-th score of its own full list (a plain store of a larger value: racy, but every value ever
+//     stored is a valid bound — k rows at least that good exist) and read unsynchronised; scores >= it are candidates, the exact
+//     (score desc, index asc) order is decided at insertion.  No seed pass: a wave's list fills on its first tile and the insertions
+//     die out like k ln(n / k).
+//   * at the end the eight lists per query meet in LDS (the query image is no longer needed) and threads 0..63 merge them: the
+//     kernel's output is one list per workgroup and query, as before.
 constexpr int GS_WAVES = 8, GS_BM = GS_WAVES * 32;
-
-__device__ __forceinline__ void gal_barrier() {               // orders LDS traffic only (does not drain vmcnt: the row prefetch stays in flight)
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
 
 __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const GalArgs p) {
     constexpr int BN = GAL_BN, TN = BN / 32;
     extern __shared__ v4f gsm[];
     const int K = p.dim, K4 = K >> 2, chunks = K / 64, k = p.k;
-    v4f* const Ql = gsm;                                                   // [64][K4], column ^ (row & 15)
-    float* const tau_s = reinterpret_cast<float*>(Ql + BN * K4);
-    int* const tau_i = reinterpret_cast<int*>(tau_s + BN);
-    float* const que_s = reinterpret_cast<float*>(tau_i + BN);             // [64][32]
-    int* const que_i = reinterpret_cast<int*>(que_s + BN * GAL_QCAP);
-    int* const cnt = que_i + BN * GAL_QCAP;
-    int* const overflow = cnt + BN;
+    v4f* const Ql = gsm;                                                   // [64][K4], column ^ (row & 15); later: the waves' lists
+    float* const tau = reinterpret_cast<float*>(Ql + BN * K4);             // [64] admission threshold (score of SOME wave's k-th entry)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh2 = lane >> 5;
@@ -283,25 +285,36 @@ __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const Ga
     const int tile_n = t % p.tiles_n, part = t / p.tiles_n;
     const int n0 = tile_n * BN;
     const int rt0 = part * p.tiles_per_part, rt1 = min(p.row_tiles, rt0 + p.tiles_per_part);
-    const int myq = lane < 8 ? wid * 8 + lane : -1;                        // the query whose sorted list this thread keeps
 
-    float ls[GAL_KMAX];
+    float ls[GAL_KMAX];                                                    // this wave's sorted list of query `lane` (entries >= k stay sentinels)
     int li[GAL_KMAX];
 #pragma unroll
     for (int i = 0; i < GAL_KMAX; ++i) { ls[i] = -INFINITY; li[i] = INT_MAX; }
-    for (int i = tid; i < BN * K4; i += GS_WAVES * 64) {
-        const int q = i / K4, c = i - q * K4;
-        Ql[q * K4 + (c ^ (q & 15))] = *reinterpret_cast<const v4f*>(p.q + (size_t)(n0 + q) * K + 4 * c);
+    {   // queries -> LDS: all loads of a thread first, then the writes (a load -> write chain per float4 costs a round trip each)
+        constexpr int QPT = 16;                                            // float4 per thread and pass: 512 threads x 16 = one 64 x 512 tile
+        for (int base = 0; base < BN * K4; base += GS_WAVES * 64 * QPT) {
+            v4f qv[QPT];
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) {
+                const int i = min(base + u * GS_WAVES * 64 + tid, BN * K4 - 1);
+                const int q = i / K4, c = i - q * K4;
+                qv[u] = *reinterpret_cast<const v4f*>(p.q + (size_t)(n0 + q) * K + 4 * c);
+            }
+#pragma unroll
+            for (int u = 0; u < QPT; ++u) {
+                const int i = base + u * GS_WAVES * 64 + tid;
+                if (i < BN * K4) { const int q = i / K4, c = i - q * K4; Ql[q * K4 + (c ^ (q & 15))] = qv[u]; }
+            }
+        }
     }
     if (tid < BN) {
-        float ts = -INFINITY; int ti = INT_MAX;
-        if (p.seed_i && n0 + tid < p.Q) {
+        float ts = -INFINITY;
+        if (p.seed_i && n0 + tid < p.Q) {                                  // (optional seed lists from the caller: a valid bound too)
             const size_t o = (size_t)(n0 + tid) * k + (k - 1);
-            if (p.seed_i[o] >= 0) { ts = p.seed_s[o]; ti = p.seed_i[o]; }
+            if (p.seed_i[o] >= 0) ts = p.seed_s[o];
         }
-        cnt[tid] = 0; tau_s[tid] = ts; tau_i[tid] = ti;
+        tau[tid] = ts;
     }
-    if (tid == 0) *overflow = 0;
     __syncthreads();
 
     const v4f* const qrow = Ql + fr * K4;                                  // + j * 32 * K4 + (col ^ swz)
@@ -328,10 +341,6 @@ __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const Ga
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-        // The query fragments of 8-deep step s + 1 are read at the START of step s (two register sets, pinned with sched_barrier): left to
-        // the compiler they are issued one MFMA before their use — ~100 cycles of cover for an LDS read that takes longer under eight
-        // waves' traffic, and both waves of a SIMD run the same code in step, so they wait together and the matrix pipe idles (PMC,
-        // round 3: 52 % busy).  wq[(8 kc + s) & 1] holds step s of chunk kc; the first step of a tile is read before its loop.
         v4f wq[2][TN];
         auto qfrag = [&](int gs) __attribute__((always_inline)) {          // global step index gs = 8 * chunk + s
             const int col = (2 * gs + fh2) ^ swz;
@@ -366,78 +375,82 @@ __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const Ga
             multiply(xa[0], kc);
             if (rt + 1 < rt1) { row_setup(rt + 1); load_a(xa[0]); }
         }
-        // ---- top-k epilogue
-        const long rbase = m0 + wid * 32 + 4 * fh2;
-        auto push = [&](int g_lo, int g_hi) {
+        // ---- top-k epilogue, wave-private.  C/D map: acc[j][e] = query 32 j + fr, row rbase(h) + 8 (e >> 2) + (e & 3), rbase(h) = .. + 4 h
+        const long rb0 = m0 + wid * 32;
+        const float th0 = tau[fr], th1 = tau[32 + fr];
+        unsigned pass = 0;                                                  // bit e: acc[0][e] is a candidate, bit 16 + e: acc[1][e]
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int qi = j * 32 + fr;
-                const float ts = tau_s[qi];
-                const int ti = tau_i[qi];
+        for (int e = 0; e < 16; ++e) {
+            const bool dead = rb0 + 4 * fh2 + 8 * (e >> 2) + (e & 3) >= p.G;
+            acc[0][e] = dead ? -INFINITY : (acc[0][e] + 1.0f) / 2.0f;       // compareFaces' mapped score, as the reference computes it
+            acc[1][e] = dead ? -INFINITY : (acc[1][e] + 1.0f) / 2.0f;
+            pass |= acc[0][e] >= th0 ? 1u << e : 0u;
+            pass |= acc[1][e] >= th1 ? 1u << (16 + e) : 0u;
+        }
+        pass &= p.dbg & 1 ? 0u : ~0u;
+        if (__builtin_amdgcn_ballot_w64(pass != 0) != 0) {                  // rare once the lists have closed
+            const float mine_th = fh2 ? th1 : th0;
+            auto insert = [&](float s_, int gi) __attribute__((always_inline)) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    if ((e >> 2) < g_lo || (e >> 2) >= g_hi) continue;
-                    const long row = rbase + 8 * (e >> 2) + (e & 3);
-                    const float sc = (acc[j][e] + 1.0f) / 2.0f;
-                    const int gi = (int)(p.idx_base + row);
-                    if (row < p.G && !gal_better(ts, ti, sc, gi)) {
-                        const int slot = atomicAdd(&cnt[qi], 1);
-                        if (slot < GAL_QCAP) { que_s[qi * GAL_QCAP + slot] = sc; que_i[qi * GAL_QCAP + slot] = gi; }
-                        else *overflow = 1;
-                    }
+                for (int pos = 0; pos < GAL_KMAX; ++pos) {                  // one compare-exchange pass keeps all 16 slots sorted (score desc, index asc)
+                    const bool sw = gal_better(s_, gi, ls[pos], li[pos]);
+                    const float os = ls[pos]; const int oi = li[pos];
+                    ls[pos] = sw ? s_ : os; li[pos] = sw ? gi : oi;
+                    s_ = sw ? os : s_; gi = sw ? oi : gi;
                 }
+            };
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned bits = (1u << e) | (1u << (16 + e));
+                if (__builtin_amdgcn_ballot_w64((pass & bits) != 0) == 0) continue;
+                // my query is 32 h + fr: my own score for it is acc[h][e] (my row); the partner lane (^32) holds it for ITS row in acc[h][e] too,
+                // i.e. I send the score I hold for the partner's query, acc[1 - h][e]
+                const float own = fh2 ? acc[1][e] : acc[0][e];
+                const float snd = fh2 ? acc[0][e] : acc[1][e];
+                const float got = __shfl_xor(snd, 32);
+                const int r_own = (int)(p.idx_base + rb0 + 4 * fh2 + 8 * (e >> 2) + (e & 3));
+                const int r_got = (int)(p.idx_base + rb0 + 4 * (1 - fh2) + 8 * (e >> 2) + (e & 3));
+                const bool c_own = own >= mine_th, c_got = got >= mine_th;
+                if (__builtin_amdgcn_ballot_w64(c_own) != 0) { if (c_own) insert(own, r_own); }
+                if (__builtin_amdgcn_ballot_w64(c_got) != 0) { if (c_got) insert(got, r_got); }
             }
-        };
-        auto insert = [&]() {
-            if (myq >= 0) {
-                const int n = min(cnt[myq], GAL_QCAP);
-                for (int c = 0; c < n; ++c) {
-                    float s = que_s[myq * GAL_QCAP + c];
-                    int gi = que_i[myq * GAL_QCAP + c];
-#pragma unroll
-                    for (int pos = 0; pos < GAL_KMAX; ++pos) {
-                        const bool sw = gal_better(s, gi, ls[pos], li[pos]);
-                        const float os = ls[pos]; const int oi = li[pos];
-                        ls[pos] = sw ? s : os; li[pos] = sw ? gi : oi;
-                        s = sw ? os : s; gi = sw ? oi : gi;
-                    }
-                }
-                if (n > 0) {
-                    int km1 = k - 1;
+            // publish: the k-th entry of a full list bounds the global k-th from below
+            int km1 = k - 1;
 #if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("" : "+v"(km1));
+            asm volatile("" : "+v"(km1));                                   // (keeps the 16 position tests on the vector side)
 #endif
-                    float ts = ls[0]; int ti = li[0];
+            float ts = ls[0]; int ti = li[0];
 #pragma unroll
-                    for (int pos = 1; pos < GAL_KMAX; ++pos) { ts = pos == km1 ? ls[pos] : ts; ti = pos == km1 ? li[pos] : ti; }
-                    if (ti != INT_MAX && gal_better(ts, ti, tau_s[myq], tau_i[myq])) { tau_s[myq] = ts; tau_i[myq] = ti; }
-                }
-                cnt[myq] = 0;
-            }
-        };
-        push(0, 4);
-        gal_barrier();
-        if (*overflow) {                                                    // (workgroup-uniform: read after the barrier)
-            gal_barrier();
-            if (tid < BN) cnt[tid] = 0;
-            if (tid == 0) *overflow = 0;
-            gal_barrier();
-            for (int g = 0; g < 8; ++g) {                                   // eight rounds of 32 rows (4 waves x 8 rows): a queue holds 32
-                if ((wid >> 2) == (g & 1)) push(g >> 1, (g >> 1) + 1);
-                gal_barrier();
-                insert();
-                gal_barrier();
-            }
-        } else {
-            insert();
-            gal_barrier();                                                  // lists / thresholds / counters settled before the next tile's pushes
+            for (int pos = 1; pos < GAL_KMAX; ++pos) { ts = pos == km1 ? ls[pos] : ts; ti = pos == km1 ? li[pos] : ti; }
+            if (ti != INT_MAX && ts > tau[lane]) tau[lane] = ts;
         }
     }
-    if (myq >= 0 && n0 + myq < p.Q) {
-        const size_t o = ((size_t)part * p.Q + n0 + myq) * k;
+    // ---- the eight waves' lists of a query -> one list per workgroup
+    __syncthreads();                                                        // every wave is done with the query image
+    float* const Ls = reinterpret_cast<float*>(Ql);                         // [8 waves][64 queries][16]
+    int* const Li = reinterpret_cast<int*>(Ls + GS_WAVES * BN * GAL_KMAX);
 #pragma unroll
-        for (int pos = 0; pos < GAL_KMAX; ++pos)
-            if (pos < k) { p.ps[o + pos] = li[pos] == INT_MAX ? -1.0f : ls[pos]; p.pi[o + pos] = li[pos] == INT_MAX ? -1 : li[pos]; }
+    for (int pos = 0; pos < GAL_KMAX; ++pos) { Ls[(wid * BN + lane) * GAL_KMAX + pos] = ls[pos]; Li[(wid * BN + lane) * GAL_KMAX + pos] = li[pos]; }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Q) {
+        int head[GS_WAVES];
+#pragma unroll
+        for (int w = 0; w < GS_WAVES; ++w) head[w] = 0;
+        const size_t o = ((size_t)part * p.Q + n0 + tid) * k;
+        for (int pos = 0; pos < k; ++pos) {                                 // k rounds of "best head of the eight sorted lists"
+            float bs = -INFINITY; int bi = INT_MAX, bw = -1;
+#pragma unroll
+            for (int w = 0; w < GS_WAVES; ++w) {
+                const int hd = min(head[w], GAL_KMAX - 1);
+                const float s_ = Ls[(w * BN + tid) * GAL_KMAX + hd];
+                const int i_ = Li[(w * BN + tid) * GAL_KMAX + hd];
+                if (head[w] < GAL_KMAX && i_ != INT_MAX && (bw < 0 || gal_better(s_, i_, bs, bi))) { bs = s_; bi = i_; bw = w; }
+            }
+#pragma unroll
+            for (int w = 0; w < GS_WAVES; ++w) head[w] += w == bw ? 1 : 0;
+            p.ps[o + pos] = bw < 0 ? -1.0f : bs;
+            p.pi[o + pos] = bw < 0 ? -1 : bi;
+        }
     }
 }
 
@@ -446,7 +459,9 @@ static bool gallery_scan_ok(int dim) {
     if (on < 0) { const char* e = getenv("FACEHIP_GALLERY_SCAN"); on = e ? atoi(e) : 1; }   // (0 = the round-2 kernel: A / B timing)
     return on && dim <= 512;
 }
-static size_t gallery_scan_lds(int dim) { return (size_t)GAL_BN * (dim / 4) * 16 + (size_t)GAL_BN * (8 + GAL_QCAP * 8 + 4) + 64; }
+static size_t gallery_scan_lds(int dim) {                                  // the query image (>= the 64 KB the final lists need) + the thresholds
+    return std::max((size_t)GAL_BN * (dim / 4) * 16, (size_t)GS_WAVES * GAL_BN * GAL_KMAX * 8) + (size_t)GAL_BN * 4;
+}
 
 // parts the row range is cut into for a gallery of G rows and a query batch of Q (the caller sizes its partial-list buffers with it)
 int gallery_parts(long G, int Q, int dim, int* tiles_per_part) {
@@ -477,6 +492,7 @@ void launch_gallery_topk(const float* gal, long G, int dim, const float* qpacked
     a.gal = gal; a.q = qpacked; a.zeros = conv_zero_line(); a.idx_base = idx_base; a.dim = dim; a.Q = Q; a.k = k;
     a.tiles_n = (Q + GAL_BN - 1) / GAL_BN;
     a.ps = part_score; a.pi = part_idx;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("FACEHIP_GAL_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     constexpr long GAL_SEED_ROWS = 4096;
     const bool scan = gallery_scan_ok(dim);
     const long bm = scan ? GS_BM : GAL_BM;
@@ -492,7 +508,7 @@ void launch_gallery_topk(const float* gal, long G, int dim, const float* qpacked
         if (scan) hipLaunchKernelGGL(gallery_scan_kernel, dim3((unsigned)(parts * a.tiles_n)), dim3(GS_WAVES * 64), lds, s, a);
         else hipLaunchKernelGGL(gallery_topk_kernel, dim3((unsigned)(parts * a.tiles_n)), dim3(256), 0, s, a);
     };
-    if (G >= 16 * GAL_SEED_ROWS && seed_score && seed_idx) {
+    if (!scan && G >= 16 * GAL_SEED_ROWS && seed_score && seed_idx) {   // (gallery_scan_kernel needs no seed pass)
         a.G = GAL_SEED_ROWS;
         a.row_tiles = (int)(GAL_SEED_ROWS / bm);
         const int sp = gallery_parts(a.G, Q, dim, &a.tiles_per_part);
