@@ -52,6 +52,7 @@ struct GalArgs {
     const float* seed_s;    // optional [Q][k]: exact top-k of a PREFIX of the gallery — its k-th entry is a valid admission threshold for
     const int* seed_i;      // the whole scan (k rows at least as good exist), so the per-workgroup lists start almost closed
     int dbg;                // tuning only (FACEHIP_GAL_DBG): 1 = no top-k epilogue, 2 = no MFMAs, 4 = no row loads
+    unsigned* tau_g;        // gallery_scan_kernel: [tiles_n * 64] admission thresholds shared by ALL workgroups (order-preserving uint keys)
 };
 
 __device__ __forceinline__ bool gal_better(float s1, int i1, float s2, int i2) { return s1 > s2 || (s1 == s2 && i1 < i2); }
@@ -267,6 +268,9 @@ __global__ __launch_bounds__(256, 2) void gallery_topk_kernel(const GalArgs p) {
 //   * at the end the eight lists per query meet in LDS (the query image is no longer needed) and threads 0..63 merge them: the
 //     kernel's output is one list per workgroup and query, as before.
 constexpr int GS_WAVES = 8, GS_BM = GS_WAVES * 32;
+// float <-> unsigned key with the same order (so that an integer atomicMax is a float max): negative floats flip all bits, others the sign
+__device__ __forceinline__ unsigned gal_key(float f) { const unsigned u = __builtin_bit_cast(unsigned, f); return (u & 0x80000000u) ? ~u : u | 0x80000000u; }
+__device__ __forceinline__ float gal_unkey(unsigned k) { return __builtin_bit_cast(float, (k & 0x80000000u) ? k & 0x7fffffffu : ~k); }
 
 __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const GalArgs p) {
     constexpr int BN = GAL_BN, TN = BN / 32;
@@ -307,14 +311,7 @@ __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const Ga
             }
         }
     }
-    if (tid < BN) {
-        float ts = -INFINITY;
-        if (p.seed_i && n0 + tid < p.Q) {                                  // (optional seed lists from the caller: a valid bound too)
-            const size_t o = (size_t)(n0 + tid) * k + (k - 1);
-            if (p.seed_i[o] >= 0) ts = p.seed_s[o];
-        }
-        tau[tid] = ts;
-    }
+    if (tid < BN) tau[tid] = -INFINITY;
     __syncthreads();
 
     const v4f* const qrow = Ql + fr * K4;                                  // + j * 32 * K4 + (col ^ swz)
@@ -325,8 +322,8 @@ __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const Ga
     auto row_setup = [&](int rt) __attribute__((always_inline)) {
         const long myrow = (long)rt * GS_BM + wid * 32 + fr;
         const bool live = myrow < p.G;
-        a_ptr = (live ? p.gal + (size_t)myrow * K : p.zeros) + fh2 * 4;     // dead rows read the zero line (and are masked in the epilogue)
-        a_step = live ? 64 : 0;
+        a_ptr = (live && !(p.dbg & 4) ? p.gal + (size_t)myrow * K : p.zeros) + fh2 * 4;     // dead rows read the zero line (and are masked in the epilogue)
+        a_step = live && !(p.dbg & 4) ? 64 : 0;
     };
     auto load_a = [&](v4f (&x)[8]) __attribute__((always_inline)) {
 #pragma unroll
@@ -336,6 +333,9 @@ __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const Ga
     if (rt0 < rt1) { row_setup(rt0); load_a(xa[0]); }
     for (int rt = rt0; rt < rt1; ++rt) {
         const long m0 = (long)rt * GS_BM;
+        // the chip-wide threshold of this lane's query (any workgroup's published k-th score: after the first round of tiles it is the
+        // top-k of >= 60 000 rows, and hardly anything passes any more).  Loaded now, used in the epilogue: its latency hides in the K loop.
+        const unsigned tg_key = __hip_atomic_load(p.tau_g + n0 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         v16f acc[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -353,10 +353,15 @@ __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const Ga
                 const int gs = kc * 8 + s;
                 if (gs + 1 < chunks * 8) qfrag(gs + 1);
                 __builtin_amdgcn_sched_barrier(0);
+                if (p.dbg & 2) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[j][s] += x[s][0] * wq[gs & 1][j][0] + x[s][1] * wq[gs & 1][j][1] + x[s][2] + x[s][3];
+                } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x[s][e], wq[gs & 1][j][e], acc[j], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -377,6 +382,10 @@ __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const Ga
         }
         // ---- top-k epilogue, wave-private.  C/D map: acc[j][e] = query 32 j + fr, row rbase(h) + 8 (e >> 2) + (e & 3), rbase(h) = .. + 4 h
         const long rb0 = m0 + wid * 32;
+        {
+            const float tg = gal_unkey(tg_key);
+            if (tg > tau[lane]) tau[lane] = tg;                             // (same wave reads it back below: LDS operations of a wave stay in order)
+        }
         const float th0 = tau[fr], th1 = tau[32 + fr];
         unsigned pass = 0;                                                  // bit e: acc[0][e] is a candidate, bit 16 + e: acc[1][e]
 #pragma unroll
@@ -422,7 +431,10 @@ __global__ __launch_bounds__(GS_WAVES * 64, 2) void gallery_scan_kernel(const Ga
             float ts = ls[0]; int ti = li[0];
 #pragma unroll
             for (int pos = 1; pos < GAL_KMAX; ++pos) { ts = pos == km1 ? ls[pos] : ts; ti = pos == km1 ? li[pos] : ti; }
-            if (ti != INT_MAX && ts > tau[lane]) tau[lane] = ts;
+            if (ti != INT_MAX && ts > tau[lane]) {
+                tau[lane] = ts;
+                atomicMax(p.tau_g + n0 + lane, gal_key(ts));
+            }
         }
     }
     // ---- the eight waves' lists of a query -> one list per workgroup
@@ -505,9 +517,15 @@ void launch_gallery_topk(const float* gal, long G, int dim, const float* qpacked
         }
     }
     auto launch = [&](int parts) {
-        if (scan) hipLaunchKernelGGL(gallery_scan_kernel, dim3((unsigned)(parts * a.tiles_n)), dim3(GS_WAVES * 64), lds, s, a);
+        if (scan) {
+            // chip-wide thresholds start at key 0 (below every float): the caller's seed_score buffer holds >= ceil64(Q) words
+            a.tau_g = reinterpret_cast<unsigned*>(seed_score);
+            (void)hipMemsetAsync(a.tau_g, 0, (size_t)a.tiles_n * GAL_BN * sizeof(unsigned), s);
+            hipLaunchKernelGGL(gallery_scan_kernel, dim3((unsigned)(parts * a.tiles_n)), dim3(GS_WAVES * 64), lds, s, a);
+        }
         else hipLaunchKernelGGL(gallery_topk_kernel, dim3((unsigned)(parts * a.tiles_n)), dim3(256), 0, s, a);
     };
+    if (scan && !seed_score) throw std::runtime_error("gallery: the scan kernel needs the seed_score scratch (>= ceil64(Q) words)");
     if (!scan && G >= 16 * GAL_SEED_ROWS && seed_score && seed_idx) {   // (gallery_scan_kernel needs no seed pass)
         a.G = GAL_SEED_ROWS;
         a.row_tiles = (int)(GAL_SEED_ROWS / bm);
