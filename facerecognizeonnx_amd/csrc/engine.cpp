@@ -683,11 +683,11 @@ void Gallery::topk_dev(const float* q, int Q, int k, float* out_score, int* out_
     if (qrows > Q) FH_HIP(hipMemsetAsync(qpack_.as<float>() + (size_t)Q * dim_, 0, (size_t)(qrows - Q) * dim_ * sizeof(float), s));
     FH_HIP(hipMemcpyAsync(qpack_.p, q, (size_t)Q * dim_ * sizeof(float), hipMemcpyDeviceToDevice, s));
     int tpp = 0;
-    const int parts = n_ > 0 ? gallery_parts(n_, Q, dim_, &tpp) : 0;
+    const int parts = n_ > 0 ? gallery_parts(n_, Q, &tpp) : 0;
     ps_.ensure((size_t)std::max(parts, 1) * Q * k * sizeof(float));
     pi_.ensure((size_t)std::max(parts, 1) * Q * k * sizeof(int));
     // ONE pass over the gallery: dot products stay in the MFMA accumulators, per-workgroup top-k lists come out (gallery.hip)
-    seed_s_.ensure(std::max((size_t)Q * k, (size_t)qrows) * sizeof(float));      // (also the scan kernel's chip-wide thresholds: ceil64(Q) words)
+    seed_s_.ensure((size_t)Q * k * sizeof(float));
     seed_i_.ensure((size_t)Q * k * sizeof(int));
     launch_gallery_topk(rows_.as<float>(), n_, dim_, qpack_.as<float>(), Q, k, base_, ps_.as<float>(), pi_.as<int>(), seed_s_.as<float>(),
                         seed_i_.as<int>(), s);

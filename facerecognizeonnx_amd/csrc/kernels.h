@@ -218,7 +218,7 @@ void launch_l2_normalize(const float* in, float* out, int n, int dim, hipStream_
 // compareFaces generalised to 1:N (src/face_recognizer.cpp:320-334): top-k of (dot+1)/2 ranked (score desc, gallery index asc).
 // gallery.hip: ONE streaming pass — gallery rows x queries on the matrix cores, per-workgroup top-k lists [gallery_parts][Q][k] kept in
 // LDS while the rows go by (no G x Q matrix in memory); then launch_topk_merge.  qpacked = [ceil64(Q)][dim], zero rows behind Q.
-int gallery_parts(long G, int Q, int dim, int* tiles_per_part);
+int gallery_parts(long G, int Q, int* tiles_per_part);
 void launch_gallery_topk(const float* gal, long G, int dim, const float* qpacked, int Q, int k, long idx_base, float* part_score, int* part_idx,
                          float* seed_score, int* seed_idx, hipStream_t s);      // seed_*: [Q][k] scratch (threshold pre-pass of large galleries)
 void launch_label(const float* best_score, const int* best_idx, int n, float thr, int* labels, hipStream_t s);
