@@ -60,9 +60,12 @@ def parse():
     ap.add_argument("--gallery", type=int, default=0, help="config C4/C5: also match every embedding against a gallery of this many "
                     "512-d rows (row-sharded over the ranks; per-rank top-k all-gathered and merged)")
     ap.add_argument("--topk", type=int, default=16)
-    ap.add_argument("--overlap", action="store_true", help="e2e: streaming form (fh_pipeline_submit_dev) — the detector of batch k+1 runs "
-                    "on its own HIP stream beside the recogniser of batch k (+1.6 to 3.6 %% measured).  Not the default because per-kernel "
-                    "durations then include time-sharing with the other network's kernels, which blurs the roofline attribution")
+    ap.add_argument("--serial", action="store_true", help="e2e: one batch at a time on one stream (fh_pipeline_run_dev).  The default since "
+                    "round 3 is the library's streaming form (fh_pipeline_submit_dev): the detector of batch k+1 runs on its own HIP stream "
+                    "beside the recogniser of batch k (+4.4 %% measured); every batch is complete inside the timed region (device-wide "
+                    "synchronise on both sides).  The per-kernel roofline leg always runs the serial form, so that a kernel's duration is "
+                    "its own; the line carries both rates")
+    ap.add_argument("--overlap", action="store_true", help="(accepted for compatibility: the streaming form is the default now)")
     ap.add_argument("--from-host", action="store_true", help="secondary measurement: frames start in pinned HOST memory and are "
                     "uploaded over PCIe, double-buffered on a side stream (the PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--recogniser", default="r50", choices=["r50", "mbf"], help="r50 = w600k_r50 (the reference's model, headline); "
@@ -382,11 +385,13 @@ def main():
                 det.detect_batch_dev(data.data_ptr(), B, 640, 640, faces.data_ptr(), F, counts.data_ptr(),
                                      args.score_thr, args.nms_thr, stream=stream)
                 return B
-        elif not args.overlap or args.from_host or args.gallery:
-            def step():
+        else:
+            def step_serial():
                 return fa.pipeline_run_dev(det, rec, data.data_ptr(), B, 640, 640, F, faces.data_ptr(), frame_of.data_ptr(),
                                            emb.data_ptr(), args.score_thr, args.nms_thr, stream)
-        else:
+            step = step_serial
+        pipelined = args.workload == "e2e" and not args.serial and not args.from_host and not args.gallery
+        if pipelined:
             # Streaming form (fh_pipeline_submit_dev): the detector of batch k+1 is queued on its own HIP stream and
             # runs beside the recogniser of batch k (HBM-bound next to MFMA-bound work); no host sync per batch.
             # A ring of 3 per-batch result buffers with event back-pressure keeps at most 3 batches in flight.
@@ -473,10 +478,11 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     units = 0
-    marks[0].record()
+    mark_stream = locals().get("s_rec")                                   # streaming form: a batch ends on the recogniser's stream
+    marks[0].record(mark_stream) if mark_stream is not None else marks[0].record()
     for i in range(args.steps):
         units += step()
-        marks[i + 1].record()
+        marks[i + 1].record(mark_stream) if mark_stream is not None else marks[i + 1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -486,6 +492,17 @@ def main():
     # Kernel-level roofline leg: the same steps again with the library's per-launch HIP events switched on.
     # It runs right AFTER the timed region (not inside it) because the ~250 event records per step cost
     # ~6 % of the step (22.8 vs 21.5 ms); `value` must not carry the instrumentation.
+    serial_dt = None
+    if locals().get("pipelined"):                                         # the same K steps once more, one batch at a time on one stream
+        step = step_serial
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        serial_dt = time.perf_counter() - ts0
     ms, fl, by = (C.c_double * NTAGS)(), (C.c_double * NTAGS)(), (C.c_double * NTAGS)()
     ln = (C.c_longlong * NTAGS)()
     isteps = 0
@@ -525,6 +542,10 @@ def main():
             "timed_step_ms_max": step_ms[-1] if step_ms else None,
             "timed_step_ms_source": "HIP events around each of the timed steps on the launch stream, rank 0 (value / ms_per_step stay the "
                                     "barrier-bracketed wall clock, max over ranks)",
+            "serial_reference": None if serial_dt is None else {
+                "ms_per_step": 1e3 * serial_dt / max(args.steps, 1), "value": per_step_faces * args.steps / serial_dt, "unit": "faces/s",
+                "what": "the same steps run one batch at a time on one stream (fh_pipeline_run_dev) right after the timed region, rank 0: "
+                        "the form the per-kernel roofline numbers below are measured in"},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"e2e": f"C-headline: {B} frames 640x640 per GPU, SCRFD det_500m + decode + NMS, first {F} "
@@ -535,7 +556,7 @@ def main():
                        "score_thr": args.score_thr, "nms_thr": args.nms_thr,
                        "weights": "synthetic seeded (det seed 100, rec seed 200)" if args.recogniser == "r50" else
                                   "synthetic seeded (det seed 100), recogniser = MobileFaceNet w600k_mbf (seed 300) instead of the reference's w600k_r50",
-                       "pipelining": "serial, one stream" if (not args.overlap or args.from_host or args.gallery or args.workload != "e2e") else
+                       "pipelining": "serial, one stream" if not locals().get("pipelined") else
                                      "detector of batch k+1 on its own HIP stream beside the recogniser of batch k (<= 3 batches in flight)",
                        "input_residency": "pinned host memory, double-buffered H2D over PCIe (PCIe-inclusive)" if args.from_host
                                           else "HBM-resident before the timed region",
