@@ -9,7 +9,8 @@ run f4 --faces-per-frame 4
 run c4_gallery --gallery 1000000 --frames 64
 run c4_match --workload match --gallery 1000000 --queries 64 --topk 16
 run from_host --from-host
-run overlap --overlap
+run serial --serial
+run latency --workload latency
 run mbf_embed --workload embed --recogniser mbf
 run mbf_e2e --recogniser mbf
 ls $O
