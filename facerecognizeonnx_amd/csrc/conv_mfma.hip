@@ -302,7 +302,8 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
             part = helper_id - (r * Kh) / p.sk_q;           // position among the helpers that touch this tile
             hu += len;
         }
-        const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+        const int gtile = tile + p.tile0;                   // (tile0 > 0: the first tiles of this convolution ran in conv_tall_kernel)
+        const int tile_n = gtile % tiles_n, tile_m = gtile / tiles_n;
         const int m0 = tile_m * BM, n0 = tile_n * BN;
         // grouped form (Winograd's 36 GEMMs stacked along M, wt_group_rows rows each, a multiple of BM): only the weight
         // matrix depends on the group — inputs and outputs are one tall matrix
@@ -624,6 +625,173 @@ void conv_pack_weights(const float* w, int Cout, int Cin, int ks, float* dst) {
         for (int k = 0; k < Ktot; ++k) dst[(size_t)co * Kpad + k] = w[(size_t)co * Ktot + k];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_tall_kernel (round 3) — 3x3 stride-1 pad-1 convolutions with Cin % 32 == 0 on maps up to 112 wide: ONE LDS image per 32-channel
+// chunk serves all nine taps.
+//
+// conv_igemm_kernel gathers a fresh A tile per (tap, chunk): 256 rows x 128 B nine times per 32 channels, although the nine tiles are
+// the same pixels shifted — for the row-linear tile [m0, m0 + BM) tap (ky, kx) reads pixel m + (ky - 1) W + (kx - 1).  What that costs is
+// not bytes (they come from L2) but ISSUE: each 1 KB LDS-DMA piece takes its wave 60-185 cycles, 40 pieces per 64 MFMAs and wave for the
+// 256x64 tile — the kernel that runs IResNet's stage 1 (Cin = 64: 2.2 ms of the 12.8 ms step) at 105-112 TFLOP/s where the 128x128
+// tile of the wider layers reaches 117-123.  Here the A image holds the BM + 2 W + 2 consecutive pixels m0 - W - 1 .. m0 + BM + W of
+// ONE 32-channel chunk (482 rows = 61.7 KB at W = 112, beside the 16 KB weight double buffer: still two workgroups per CU) and the nine
+// taps are nine row-shifted views of it: fragment row = tile row + ky W + kx.  A traffic / 4.8, LDS-DMA pieces per MFMA / 2.6.
+//   * K order: chunk-major (for each 32-channel chunk: nine taps); the weight chunk of (chunk c, tap t) sits at k = t Cin + 32 c of the
+//     packed row, so only an address changes.
+//   * a shifted view reads a REAL neighbour where the convolution pads with zero (left / right image border, first / last row, and the
+//     pixels of the neighbouring image across a batch boundary): every lane carries a 9-bit validity mask of its fragment pixel per
+//     32-row block and zeroes the fragment with v_cndmask (a select, not a multiply: the neighbour may hold anything).  Image rows
+//     outside the tensor come from the zero line.
+//   * swizzle: 16-byte column ^ ((LDS row >> 1) & 7), on the source side as in conv_igemm_kernel; a view's key is that of its shifted row.
+//   * tiles are row-linear as in conv_igemm_kernel, so conv_epilogue (9 bias classes, PReLU, residual, second output) is shared and
+//     nothing is wasted on maps that are no multiple of a spatial tile (56 = 3.5 x 16).
+//   * no stream-K here: launch_cfg gives this kernel the whole ROUNDS of tiles and the remainder (tile0 = the first one) to
+//     conv_igemm_kernel, whose owner / helper hand-off cuts those few tiles' K range over the whole chip.
+template <int BM, int BN, int WM, int WN, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, OCC) void conv_tall_kernel(const ConvArgs p, const int tiles_n, const int rows_a) {
+    using TL = Tile<BM, BN, WM, WN>;
+    constexpr int TM = TL::TM, TN = TL::TN, RP = TL::RP, BL = TL::BL;
+    constexpr int NPMAX = (BM + 2 * 112 + 2 + RP - 1) / RP;                // loader passes of the tallest image (W = 112)
+    extern __shared__ v4f tsm[];
+    v4f* const As = tsm;                                                   // [rows_a][8 float4], rows_a = whole loader passes
+    v4f* const Bs = tsm + (size_t)rows_a * 8;                              // [2][BN][8]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid / WN, wn = wid % WN;
+    const int W = p.W, HW = p.H * p.W, Cin = p.Cin;
+    const int M = p.B * HW;
+    const int lrow = tid >> 3;
+    const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);                         // (RP % 16 == 0: the key of row i * RP + lrow is that of lrow)
+    const int fr = lane & 31, fh2 = lane >> 5;
+    int tile;
+    {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, x = blockIdx.x & 7;
+        tile = x * q + min(x, r) + (int)(blockIdx.x >> 3);                 // XCD-contiguous tile order (as conv_igemm_kernel)
+    }
+    const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int np = rows_a / RP;
+
+    // ---- A image loader: pass i fills LDS rows i * RP + lrow <- pixel m0 - W - 1 + row (all of one 32-channel chunk, this lane's column)
+    const float* a_ptr[NPMAX];
+#pragma unroll
+    for (int i = 0; i < NPMAX; ++i) {
+        const long q = (long)m0 - W - 1 + i * RP + lrow;
+        a_ptr[i] = (i < np && q >= 0 && q < M) ? p.in + q * Cin + lqs * 4 : p.zeros;
+    }
+    int a_adv[NPMAX];
+#pragma unroll
+    for (int i = 0; i < NPMAX; ++i) a_adv[i] = a_ptr[i] == p.zeros ? 0 : 32;      // (rows that read the zero line do not walk off it)
+    const char* w_tile = reinterpret_cast<const char*>(p.wt) + (size_t)n0 * p.Kpad * 4;
+    unsigned w_off[BL];
+#pragma unroll
+    for (int i = 0; i < BL; ++i) w_off[i] = (unsigned)(((lrow + i * RP) * p.Kpad + lqs * 4) * 4);
+    v4f* const dstA = As + wid * 64;
+    v4f* const dstB = Bs + wid * 64;
+    auto load_b = [&](int c, int tap, int buf) __attribute__((always_inline)) {
+        const char* wb = w_tile + (size_t)(tap * Cin + c * 32) * 4;
+#pragma unroll
+        for (int i = 0; i < BL; ++i) lds_dma16(reinterpret_cast<const float*>(wb + w_off[i]), dstB + buf * (BN * 8) + i * RP * 8);
+    };
+
+    // ---- fragment views: block i of this wave = tile rows (wm TM + i) 32 + fr; validity of the nine taps of that pixel
+    unsigned vmask[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 32 + fr;
+        unsigned mk = 0;
+        if (m < M) {
+            const int rem = m % HW, oy = rem / W, ox = rem - oy * W;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                if ((unsigned)(oy + t / 3 - 1) < (unsigned)p.H && (unsigned)(ox + t % 3 - 1) < (unsigned)W) mk |= 1u << t;
+        }
+        vmask[i] = mk;
+    }
+    v16f acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // the epilogue's per-channel vectors (see conv_epilogue: ep), parked in LDS after the K loop
+    constexpr int EPN = (12 * BN + WM * WN * 64 - 1) / (WM * WN * 64);
+    float epv[EPN];
+#pragma unroll
+    for (int k = 0; k < EPN; ++k) {
+        const int e = tid + k * (WM * WN * 64), a = e / BN, c = e - a * BN, co = n0 + c;
+        float v = 0.f;
+        if (a < 12 && co < p.Cout) {
+            if (a < 9) { if (p.bias && (a == 0 || p.bias_cls)) v = p.bias[a * p.Cout + co]; }
+            else if (a == 9) { if (p.act == (int)Act::PRELU) v = p.slope[co]; }
+            else if (p.out2) v = a == 10 ? p.s2[co] : p.t2[co];
+        }
+        epv[k] = v;
+    }
+
+    const int NC = Cin >> 5;
+    const int rbase = (wm * TM * 32 + fr);                                 // this lane's row in the tile (block 0)
+    for (int c = 0; c < NC; ++c) {
+        __syncthreads();                                                   // every wave is done with the previous chunk's image and weight buffers
+        for (int i = 0; i < np; ++i) { lds_dma16(a_ptr[i < NPMAX ? i : 0], dstA + i * RP * 8); }
+#pragma unroll
+        for (int i = 0; i < NPMAX; ++i) a_ptr[i] += a_adv[i];
+        load_b(c, 0, 0);
+        __syncthreads();                                                   // (drains vmcnt: image + first weight chunk have landed)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int buf = tap & 1;
+            if (tap + 1 < 9) load_b(c, tap + 1, buf ^ 1);
+            const int shift = (tap / 3) * W + tap % 3;
+            const int r0 = rbase + shift;                                  // LDS row of block 0's fragment pixel under this tap
+            const int key = (r0 >> 1) & 7;                                 // (block i adds 32 i rows: same key)
+            const v4f* X = As + r0 * 8;
+            const v4f* Wt = Bs + buf * (BN * 8) + (wn * TN * 32 + fr) * 8;
+            const int wkey = (fr >> 1) & 7;
+            bool ok[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ok[i] = (vmask[i] >> tap) & 1u;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                v4f x[TM], w[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    x[i] = X[i * 32 * 8 + ((2 * s2 + fh2) ^ key)];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) x[i][e] = ok[i] ? x[i][e] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) w[j] = Wt[j * 32 * 8 + ((2 * s2 + fh2) ^ wkey)];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j][e], x[i][e], acc[i][j], 0, 0, 0);
+            }
+            if (tap + 1 < 9) __syncthreads();                              // next weight chunk landed; everyone done with this one
+        }
+    }
+    __syncthreads();                                                       // K loop over: LDS is free
+    float* const ep = reinterpret_cast<float*>(Bs);
+#pragma unroll
+    for (int k = 0; k < EPN; ++k) {
+        const int e = tid + k * (WM * WN * 64);
+        if (e < 12 * BN) ep[e] = epv[k];
+    }
+    __syncthreads();
+    conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane, -1, -1, ep);
+}
+
+static int tall_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FACEHIP_CONV_TALL"); v = e ? atoi(e) : 1; }       // (0 = conv_igemm_kernel everywhere: A / B timing)
+    return v;
+}
+
 int conv_pick_cfg(long M, int Cout) {
     // padded-column waste per candidate tile width; prefer the wider tile when it costs <= 10 % more
     auto cols = [&](int bn) { return (Cout + bn - 1) / bn * bn; };
@@ -710,14 +878,49 @@ static int sk_margin2() {
 }
 
 template <int BM, int BN, int WM, int WN, int OCC>
+static void launch_cfg_tail(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t s, const int T, const int tiles_n, const int S);
+
+template <int BM, int BN, int WM, int WN, int OCC>
 static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t s) {
     const long M = (long)a.B * a.Ho * a.Wo;
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = (a.Cout + BN - 1) / BN;
     const bool grouped = a.wt_group_rows > 0;
     const int T = tiles_m * tiles_n;
-    const int chunks = a.Kpad / 32;
     const int S = (a.cus > 0 ? a.cus : num_cus()) * resident_per_cu;
     a.zeros = conv_zero_line();
+    a.tile0 = 0;
+    // 3x3 stride-1 layers on maps up to 112 wide: the whole ROUNDS of tiles run in conv_tall_kernel (one LDS image per 32-channel chunk
+    // for all nine taps), the remainder below with tile0 = the first tile it did not take
+    if constexpr (BM == 256 && BN == 64)
+    if (tall_enabled() && !grouped && !a.sc_in && a.ks == 3 && a.stride == 1 && a.pad == 1 && (a.Cin & 31) == 0 &&
+        a.H == a.Ho && a.W == a.Wo && a.W <= 112 && a.n_outs == 0 && (a.Cout & 3) == 0 && a.res_mode != (int)ResMode::UP2X && T >= S) {
+        constexpr int RPt = Tile<BM, BN, WM, WN>::RP;
+        const int rows_a = (BM + 2 * a.W + 2 + RPt - 1) / RPt * RPt;
+        const size_t lds = ((size_t)rows_a * 8 + 2 * BN * 8) * sizeof(v4f);
+        int tall_tiles = (T / S) * S;
+        tall_tiles -= tall_tiles % tiles_n;
+        if (lds <= 80 * 1024 && tall_tiles > 0) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tall_kernel<BM, BN, WM, WN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                attr_set = true;
+            }
+            KernelTimer& tt = KernelTimer::get();
+            tt.begin(s);
+            hipLaunchKernelGGL((conv_tall_kernel<BM, BN, WM, WN, OCC>), dim3((unsigned)tall_tiles), dim3(WM * WN * 64), lds, s, a, tiles_n, rows_a);
+            tt.end(s, cfg_tag, a.t_flops * ((double)tall_tiles / T), a.t_bytes * ((double)tall_tiles / T));
+            a.t_flops *= (double)(T - tall_tiles) / T; a.t_bytes *= (double)(T - tall_tiles) / T;
+            a.tile0 = tall_tiles;
+            if (tall_tiles == T) return;
+        }
+    }
+    return launch_cfg_tail<BM, BN, WM, WN, OCC>(a, resident_per_cu, cfg_tag, s, T - a.tile0, tiles_n, S);
+}
+
+template <int BM, int BN, int WM, int WN, int OCC>
+static void launch_cfg_tail(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t s, const int T, const int tiles_n, const int S) {
+    const bool grouped = a.wt_group_rows > 0;
+    const int chunks = a.Kpad / 32;
     int full = (T / S) * S;
     int R = T - full;
     int helpers = 0, owners = 0;

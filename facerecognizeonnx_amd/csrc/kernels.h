@@ -95,6 +95,7 @@ struct ConvArgs {
     unsigned* sk_err;
     unsigned sk_timeout;
     int sk_test_drop;
+    int tile0;              // filled in by launch_conv: first tile conv_igemm_kernel computes (the tiles before it ran in conv_tall_kernel)
 };
 
 // cfg: 0 = 128x128 tile, 1 = 256x64, 2 = 128x32, 3 = 64x64 (256 threads each); -1 = choose.
