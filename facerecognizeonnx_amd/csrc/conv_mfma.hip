@@ -37,6 +37,7 @@
 // owners: every segment goes to a slab and conv_fixup_kernel sums them in a second launch.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -609,7 +610,8 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_fixup_kernel(const ConvArgs
 #pragma unroll
         for (int j = 0; j < TN; ++j)
             if (i == si && j == sj) acc[i][j] = sum;
-    const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+    const int gtile = tile + p.tile0;                       // (see conv_igemm_kernel)
+    const int tile_n = gtile % tiles_n, tile_m = gtile / tiles_n;
     conv_epilogue<BM, BN, WM, WN>(p, acc, tile_m * BM, tile_n * BN, wm, wn, lane, si, sj);
 }
 
@@ -947,7 +949,10 @@ static void launch_cfg_tail(ConvArgs a, int resident_per_cu, int cfg_tag, hipStr
             int q = (int)((U + S - 1) / S);
             // do not cut segments shorter than 8 chunks — 24 for very deep K (the 25 088-deep FC: 61 slabs per tile made the fix-up kernel,
             // 16 workgroups summing them one after the other, take 35 of the layer's 80 us; 21 slabs: 48 + 20 us)
-            const int min_q = chunks < 8 ? chunks : chunks >= 256 ? 24 : 8;
+            // (the tail of a convolution whose whole rounds ran in conv_tall_kernel is a few tiles on an otherwise empty chip: cut them finer)
+            static int tail_q = -1;
+            if (tail_q < 0) { const char* e = getenv("FACEHIP_TALL_TAIL_Q"); tail_q = e ? atoi(e) : 3; }
+            const int min_q = a.tile0 > 0 ? std::min(chunks, tail_q) : chunks < 8 ? chunks : chunks >= 256 ? 24 : 8;
             if (q < min_q) q = min_q;
             const int maxp = (chunks + q - 1) / q + 1;
             if (q * sk_b_ratio() <= chunks * 2 && q < chunks && (size_t)R * maxp * BM * BN <= SK_SLAB_FLOATS) {
