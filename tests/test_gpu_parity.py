@@ -53,6 +53,10 @@ CONV_CASES = [
     (1, 13, 13, 4, 24, 3, 2, 2),
     (2, 8, 8, 152, 288, 1, 1, -1),
     (1, 10, 10, 72, 40, 1, 2, -1),
+    # >= 512 tiles of 256 rows: the whole tile rounds run in conv_tall_kernel (one LDS image per 32-channel chunk for all nine taps, border
+    # taps masked per lane: ragged map, image boundaries inside tiles), the remainder in conv_igemm_kernel with tile0 > 0 (+ its fix-up)
+    (66, 40, 52, 32, 48, 3, 1, 1),
+    (35, 61, 63, 64, 64, 3, 1, 1),
 ]
 
 
