@@ -910,7 +910,7 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
             KernelTimer& tt = KernelTimer::get();
             tt.begin(s);
             hipLaunchKernelGGL((conv_tall_kernel<BM, BN, WM, WN, OCC>), dim3((unsigned)tall_tiles), dim3(WM * WN * 64), lds, s, a, tiles_n, rows_a);
-            tt.end(s, cfg_tag, a.t_flops * ((double)tall_tiles / T), a.t_bytes * ((double)tall_tiles / T));
+            tt.end(s, 10, a.t_flops * ((double)tall_tiles / T), a.t_bytes * ((double)tall_tiles / T));
             a.t_flops *= (double)(T - tall_tiles) / T; a.t_bytes *= (double)(T - tall_tiles) / T;
             a.tile0 = tall_tiles;
             if (tall_tiles == T) return;

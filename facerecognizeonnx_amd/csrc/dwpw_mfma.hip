@@ -461,7 +461,16 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
     front_barrier();
     if (t < run1) prefetch();
     int buf = 0;
+#ifdef FACEHIP_DWPW_PROF
+    long long fph[6] = {0, 0, 0, 0, 0, 0}; long long fst0; int fnt = 0;
+#define FRONT_STAMP(i) { const long long now_ = __builtin_readcyclecounter(); fph[i] += now_ - fst0; fst0 = now_; }
+#else
+#define FRONT_STAMP(i)
+#endif
     for (; t < run1; t += wgs, buf ^= 1) {
+#ifdef FACEHIP_DWPW_PROF
+        fst0 = __builtin_readcyclecounter(); ++fnt;
+#endif
         const int cn = n, cty0 = tyi * DP_TH, ctx0 = txi * DP_TW;          // this tile (n / tyi / txi move on to the prefetched one)
         const uint8_t* frame = p.u8_src + (size_t)cn * p.u8_img_stride;
         const int sy0 = (cty0 - 1) * S - 1, sx0 = (ctx0 - 1) * S - 1;
@@ -470,9 +479,12 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
 #pragma unroll
         for (int k = 0; k < FR_SLOTS; ++k)
             if (tid + 256 * k < FR_ROWS * FR_PITCH) stage[buf][tid + 256 * k] = pf[k];
+        FRONT_STAMP(0)
         advance();
         if (t + wgs < run1) prefetch();
+        FRONT_STAMP(1)
         front_barrier();
+        FRONT_STAMP(2)
         // 2. stem.  Pass FAST: every pixel whose 3x9-byte window lies inside the frame, from the staged image — no global access, so no
         // wait on the prefetch.  Pass BORDER (only tiles that touch the frame's border, a wave-uniform test): the remaining pixels, byte by
         // byte from global memory (outside the net input = conv zero padding: 127.5 cancels against the folded bias; inside it but outside
@@ -560,6 +572,7 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
                 stem_finish(f, inmap, slow, hp);
             }
         }
+        FRONT_STAMP(3)
         front_barrier();
         // 3 + 4 merged (round 3, as dwpw_reg_kernel): a wave owns 32 pixels, lane = (pixel fr, half fh2); the depthwise 3x3 of channels
         // 8 j + 4 fh2 .. + 3 of ITS pixel is the B fragment of the pointwise MFMAs — no A tile, no barrier between the two, and the
@@ -609,6 +622,7 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            FRONT_STAMP(4)
             const int oy = cty0 + py, ox = ctx0 + pxx;
             if (oy < p.Ho && ox < p.Wo) {
                 float* __restrict__ orow = p.out1 + (((size_t)cn * p.Ho + oy) * p.Wo + ox) * p.Cout;
@@ -622,8 +636,16 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
                     *reinterpret_cast<v4f*>(orow + co) = v;
                 }
             }
+            FRONT_STAMP(5)
         }
     }
+#ifdef FACEHIP_DWPW_PROF
+    if (lane == 0 && p.slabs) {
+        long long* o = reinterpret_cast<long long*>(p.slabs) + ((size_t)blockIdx.x * 4 + wid) * 8;
+        for (int i = 0; i < 6; ++i) o[i] = fph[i];
+        o[6] = fnt;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------

@@ -328,6 +328,7 @@ void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int st
         a.B = batch; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
         a.ks = 1; a.stride = 1; a.pad = 0; a.Kpad = d.Kpad; a.act = (int)op.act;
         a.u8_src = src; a.u8_img_stride = img_stride; a.u8_step = step; a.u8_srcH = srcH; a.u8_srcW = srcW; a.u8_inH = plan_.inH; a.u8_inW = plan_.inW;
+        a.slabs = partial_.as<float>();                                      // (diagnostic builds park their phase stamps there)
         a.u8_stride = st.stride; a.stem_act = (int)st.act; a.stem_wf = P + d0.wf; a.stem_bf = P + d0.bf;
         a.stem_wfrag = reinterpret_cast<const unsigned*>(P + d0.wfr);
         a.cus = cus;

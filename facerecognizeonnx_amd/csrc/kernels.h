@@ -15,7 +15,7 @@ void hip_check(hipError_t e, const char* what);
 // Optional per-launch HIP-event timing of the network kernels (bench.py's roofline leg).
 // Tags: 0..3 = conv_igemm tile configs, 4 = depthwise conv, 5 = other graph ops, 6 = conv stream-K fix-up.
 struct KernelTimer {
-    static constexpr int kTags = 10;     // 0-3 conv tile configs, 4 dw / dwpw, 5 other, 6 fix-up, 7 Winograd GEMM, 8 Winograd transforms, 9 halo conv
+    static constexpr int kTags = 11;     // 0-3 conv tile configs, 4 dw / dwpw, 5 other, 6 fix-up, 7 Winograd GEMM, 8 Winograd transforms, 9 halo conv, 10 conv_tall_kernel
     bool enabled = false;
     void begin(hipStream_t s);
     void end(hipStream_t s, int tag, double flops, double bytes);

@@ -36,13 +36,16 @@ print("per-op us:", [round(float(np.median([ms[r * per + i] for r in range(5)]))
 L.fh_timing_enable(0)
 run(); torch.cuda.synchronize()
 ws = L.fh_det_workspace_dev(det.handle)
-nwg = 256 * 4
+nwg = 256 * 4 * 2
 buf = np.zeros((nwg, 4, 8), np.int64)
 assert L.fh_memcpy_d2h(buf.ctypes.data, ws, buf.nbytes) == 0
 live = buf[buf[..., 6] > 0]
 if len(live):
     tiles = live[:, 6].astype(np.float64)
     names = ["barrier A (prev tile's readers done + wait for prefetched loads)", "pf regs -> LDS", "issue next prefetch", "barrier B", "bias + K loop", "stores"]
+    if Cc == 16 and Cout <= 32:     # this shape runs as front_kernel (stem inside the block): its own phase list
+        names = ["window registers -> LDS (waits for the prefetched loads)", "issue next window prefetch", "barrier", "stem (bf16 MFMA, 3 terms)",
+                 "barrier + depthwise -> pointwise (register-fed)", "stores"]
     tot = 0
     for i, nm in enumerate(names):
         c = (live[:, i] / tiles).mean(); tot += c

@@ -52,6 +52,9 @@ for i in range(per):
     if tg[i] in (6, 8):
         print(f"{t*1e3:9.1f} us             {'fix-up' if tg[i] == 6 else 'winograd transform'}")
         continue
+    if tg[i] == 10:                                              # whole tile rounds of the next op in conv_tall_kernel; its remainder follows
+        print(f"{t*1e3:9.1f} us  {fl[i]/t/1e9 if t>0 else 0:7.1f} TF/s  tall   {ops[oi] if oi < len(ops) else ''}  (whole tile rounds)")
+        continue
     print(f"{t*1e3:9.1f} us  {fl[i]/t/1e9 if t>0 else 0:7.1f} TF/s  cfg{tg[i]}  {ops[oi] if oi < len(ops) else ''}")
     oi += 1
 print(f"total {tot:.3f} ms for batch {B}; {sum(fl[i] for i in range(per))/tot/1e9:.1f} TF/s overall")
