@@ -510,9 +510,9 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
             if (!inmap) a4 = v4f{0.f, 0.f, 0.f, 0.f};                       // outside the map: the depthwise zero padding
             if (store) halo[hp * 5 + g] = a4;
         };
+        static_assert(4 * (NG - 1) * 16 + 3 * 16 < DP_HALO, "every wave has NG groups: the loop has no early exit (straight-line code: the three groups interleave)");
 #pragma unroll
         for (int i = 0; i < NG; ++i) {                                      // (wave-uniform trip count: the MFMAs run with all lanes)
-            if ((wid + 4 * i) * 16 >= DP_HALO) break;
             const int hp = g_hp[i];
             bool inmap = hp >= 0, fast = inmap;
             if (!tile_inside) {
