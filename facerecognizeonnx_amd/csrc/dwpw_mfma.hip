@@ -463,6 +463,7 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
     int buf = 0;
 #ifdef FACEHIP_DWPW_PROF
     long long fph[6] = {0, 0, 0, 0, 0, 0}; long long fst0; int fnt = 0;
+    const long long fclk0 = __builtin_readcyclecounter(), frt0 = __builtin_amdgcn_s_memrealtime();   // shader clock vs the constant 100 MHz counter
 #define FRONT_STAMP(i) { const long long now_ = __builtin_readcyclecounter(); fph[i] += now_ - fst0; fst0 = now_; }
 #else
 #define FRONT_STAMP(i)
@@ -644,6 +645,7 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
         long long* o = reinterpret_cast<long long*>(p.slabs) + ((size_t)blockIdx.x * 4 + wid) * 8;
         for (int i = 0; i < 6; ++i) o[i] = fph[i];
         o[6] = fnt;
+        o[7] = (__builtin_readcyclecounter() - fclk0) * 1000 / ((long long)__builtin_amdgcn_s_memrealtime() - frt0 + 1);   // cycles per 10 us -> MHz / 100 ... = MHz x 10
     }
 #endif
 }
@@ -687,6 +689,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
     v4f* const dwl = halo + DP_HALO * PQ;                                  // [10][CQ]: 9 taps + bias
     v4f* const Wl = dwl + 10 * CQ;                                         // [STEPS][2][Cout]: A fragments (n = row, 4 k of half h)
     float* const pwb = reinterpret_cast<float*>(Wl + STEPS * 2 * p.Cout);  // [32 * TN] pointwise bias (zero behind Cout)
+    int* const nxt = reinterpret_cast<int*>(pwb + 32 * TN);                // [2] tile of the iteration after next (see the tile loop)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -714,12 +717,25 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) wrow[jn] = h * Cout + min(32 * jn + r, Cout - 1);   // rows >= Cout: any valid address (their columns are never stored)
 
-    // ---- tiles: XCD x owns a contiguous run, its workgroups walk it side by side
-    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, wgs = gridDim.x >> 3;       // (gridDim.x is a multiple of 8)
+    // ---- tiles: XCD x owns a contiguous run (neighbouring tiles share halo rows in that XCD's L2), DEALT DYNAMICALLY: a workgroup takes
+    // the next tile of its XCD's run from an atomic counter, and from the other XCDs' runs once its own is empty.  With the static deal
+    // (tile t, t + wgs, ...) the phase stamps showed the slowest wave of a launch 12-33 % above the mean (CUs and XCDs do not run at one
+    // speed) and the kernel ends with the slowest.  The counter is read two tiles ahead by one thread (the atomic is issued before the
+    // K loop, its result parked in LDS after it), so nobody waits for it.
+    const int xcd = blockIdx.x & 7;
     const int q8 = tiles_total >> 3, r8 = tiles_total & 7;
-    const int run0 = xcd * q8 + min(xcd, r8), run1 = run0 + q8 + (xcd < r8 ? 1 : 0);
     const int per_img = tiles_x * tiles_y;
-
+    int* const ctr = p.tile_ctr;                                           // [8], zero at launch
+    const int my_r0 = xcd * q8 + min(xcd, r8), my_len = q8 + (xcd < r8 ? 1 : 0);
+    auto steal = [&]() -> int {                                           // (thread 0 only) own run empty: the other XCDs' runs, nearest first
+        for (int kx = 1; kx < 8; ++kx) {
+            const int x = (xcd + kx) & 7;
+            const int i = atomicAdd(ctr + x, 1);
+            if (i < q8 + (x < r8 ? 1 : 0)) return x * q8 + min(x, r8) + i;
+        }
+        return -1;
+    };
+    auto take = [&]() -> int { const int i = atomicAdd(ctr + xcd, 1); return i < my_len ? my_r0 + i : steal(); };
     // halo of tile t: global -> registers (issued, not waited for).  Per thread and item the byte offset relative to the tile's halo
     // origin is tile-invariant (voff); per tile: one add each, and on tiles that touch the left / right border a select.
     v4f pf[NPF];
@@ -752,16 +768,18 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 #pragma unroll
         for (int k = 0; k < NPF; ++k) pf[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo[k], 0, 0));
     };
-    int t = run0 + wg;
-    if (t < run1) prefetch(t);
-    front_barrier();                                                        // dwl / Wl / pwb written by all waves
+    if (tid == 0) { const int a0 = take(); nxt[0] = a0; nxt[1] = a0 >= 0 ? take() : -1; }
+    front_barrier();                                                        // dwl / Wl / pwb / nxt written
+    int t = nxt[0], tn = nxt[1];
+    if (t >= 0) prefetch(t);
 #ifdef FACEHIP_DWPW_PROF
     long long ph[6] = {0, 0, 0, 0, 0, 0}; long long st0; int ntiles = 0;
+    const long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
 #define DWPW_STAMP(i) { const long long now_ = __builtin_readcyclecounter(); ph[i] += now_ - st0; st0 = now_; }
 #else
 #define DWPW_STAMP(i)
 #endif
-    for (; t < run1; t += wgs) {
+    for (int it = 0; t >= 0; ++it) {
         const int n = t / per_img, rem = t - n * per_img;
         const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
         const int ty0 = tyi * DP_TH, tx0 = txi * DP_TW;
@@ -769,6 +787,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
         st0 = __builtin_readcyclecounter(); ++ntiles;
 #endif
         front_barrier();                                                    // every wave is done reading the previous tile's halo
+        if (it > 0) tn = nxt[(it + 1) & 1];                                 // (thread 0 parked it there at the end of the previous iteration)
         DWPW_STAMP(0)
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
@@ -776,7 +795,9 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
             if (i < DP_HALO * CQ) halo[i + i / CQ] = pf[k];              // pixel pitch PQ = CQ + 1
         }
         DWPW_STAMP(1)
-        if (t + wgs < run1) prefetch(t + wgs);
+        if (tn >= 0) prefetch(tn);
+        int gi = 0;
+        if (tid == 0 && tn >= 0) gi = atomicAdd(ctr + xcd, 1);              // the tile after next: issued now, looked at after the K loop
         DWPW_STAMP(2)
         front_barrier();                                                    // halo complete
         DWPW_STAMP(3)
@@ -850,6 +871,8 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
                     *reinterpret_cast<v4f*>(orow + co) = v;
                 }
         }
+        if (tid == 0) nxt[it & 1] = tn < 0 ? -1 : (gi < my_len ? my_r0 + gi : steal());
+        t = tn;
         DWPW_STAMP(5)
     }
 #ifdef FACEHIP_DWPW_PROF
@@ -857,6 +880,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
         long long* o = reinterpret_cast<long long*>(p.slabs) + ((size_t)blockIdx.x * 4 + wid) * 8;
         for (int i = 0; i < 6; ++i) o[i] = ph[i];
         o[6] = ntiles;
+        o[7] = (__builtin_readcyclecounter() - clk0) * 1000 / ((long long)__builtin_amdgcn_s_memrealtime() - rt0 + 1);
     }
 #endif
 }
@@ -868,7 +892,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 // dwpw_kernel (lane = 16-byte channel column, 4 lanes per 64-byte pixel) keeps them coalesced and stays.
 
 static size_t dwpw_reg_lds(int CQ, int Cout, int TN) {
-    return ((size_t)DP_HALO * (CQ + 1) + 10 * CQ + (size_t)(CQ / 2) * 2 * Cout) * 16 + (size_t)32 * TN * 4;
+    return ((size_t)DP_HALO * (CQ + 1) + 10 * CQ + (size_t)(CQ / 2) * 2 * Cout) * 16 + (size_t)32 * TN * 4 + 16;
 }
 static bool dwpw_reg_enabled() {
     static int v = -1;
@@ -892,7 +916,7 @@ static void launch_dwpw_reg_cfg(const ConvArgs& a, hipStream_t s) {
 }
 // true = launched.  Instantiated for SCRFD-500M's stride-1 blocks (C = 16 / 40 / 64 / 72) with any Cout <= 96.
 static bool launch_dwpw_reg(const ConvArgs& a, hipStream_t s) {
-    if (!dwpw_reg_enabled() || a.dw_stride != 1 || a.u8_src || a.Cout % 4 || a.Cout > 96 || a.H != a.Ho || a.W != a.Wo) return false;
+    if (!dwpw_reg_enabled() || a.dw_stride != 1 || a.u8_src || a.Cout % 4 || a.Cout > 96 || a.H != a.Ho || a.W != a.Wo || !a.tile_ctr) return false;
     if (a.act != (int)Act::NONE && a.act != (int)Act::RELU) return false;
     if ((long)a.H * a.W * a.Cin * 4 >= (1L << 31)) return false;            // one image must fit a 32-bit buffer range
     const int tn = (a.Cout + 31) / 32;

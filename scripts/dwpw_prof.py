@@ -51,5 +51,10 @@ if len(live):
         c = (live[:, i] / tiles).mean(); tot += c
         print(f"{c:9.0f} cycles/tile  {nm}")
     print(f"{tot:9.0f} cycles/tile total; {tiles.mean():.1f} tiles per workgroup, {len(live) // 4} workgroups")
+    wave_tot = live[:, :6].sum(axis=1).astype(np.float64)      # cycles a wave spent in its tile loop: the kernel ends with the SLOWEST one
+    print(f"per-wave loop cycles: min {wave_tot.min():.0f}, median {np.median(wave_tot):.0f}, mean {wave_tot.mean():.0f}, max {wave_tot.max():.0f}  "
+          f"(max / mean = {wave_tot.max() / wave_tot.mean():.2f})")
+    mhz = live[:, 7] / 10.0                                     # shader cycles per 100 MHz tick x 100
+    print(f"in-kernel shader clock (s_memtime / s_memrealtime over the tile loop): median {np.median(mhz):.0f} MHz, min {mhz.min():.0f}, max {mhz.max():.0f}")
 else:
     print("no stamps: library not built with -DFACEHIP_DWPW_PROF")
