@@ -678,6 +678,30 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
 // compiler's wait for the prefetched registers becomes the exact `vmcnt(stores + later loads)` instead of vmcnt(0): the ISA showed
 // vmcnt(21)..(9) as intended, the layers ran no faster and the 16-channel layers slower.
 // C % 8 == 0 (CQ = C / 4 even), Cout % 4 == 0, Cout <= 32 * TN.
+// A returning atomic add whose result is NOT waited for at the issue: HIP's atomicAdd goes through the compiler's wave-level atomic
+// optimiser (reduce, one lane adds, readfirstlane broadcast) and that broadcast puts `s_waitcnt vmcnt(0)` right behind the instruction —
+// 1-3 us of the issuing wave per tile, and the other waves of the workgroup wait for it at the next barrier (measured: 13 k -> 23 k
+// cycles per tile).  Here lane 0 of the calling wave issues the instruction (EXEC narrowed inside the asm block, wave-uniform caller),
+// the result lands in `dst` some time later, and tile_ticket_wait() — the ONLY place `dst` may be read after — drains the counter.
+__device__ __forceinline__ void tile_ticket_issue(unsigned& dst, int* counter) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long saved;
+    const unsigned long long addr = (unsigned long long)counter;
+    const unsigned one = 1u;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
+                 : "+v"(dst), "=&s"(saved) : "v"(addr), "v"(one) : "memory");
+#else
+    (void)dst; (void)counter;
+#endif
+}
+__device__ __forceinline__ void tile_ticket_wait(unsigned& dst) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory");
+#else
+    (void)dst;
+#endif
+}
+
 template <int CQ, int TN, int OCC>
 __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_total) {
     static_assert(CQ % 2 == 0, "whole 8-channel MFMA steps");
@@ -796,8 +820,8 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
         }
         DWPW_STAMP(1)
         if (tn >= 0) prefetch(tn);
-        int gi = 0;
-        if (tid == 0 && tn >= 0) gi = atomicAdd(ctr + xcd, 1);              // the tile after next: issued now, looked at after the K loop
+        unsigned gi = 0;
+        if (wid == 0 && tn >= 0) tile_ticket_issue(gi, ctr + xcd);          // the tile after next: issued now (lane 0), looked at after the K loop
         DWPW_STAMP(2)
         front_barrier();                                                    // halo complete
         DWPW_STAMP(3)
@@ -871,7 +895,10 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
                     *reinterpret_cast<v4f*>(orow + co) = v;
                 }
         }
-        if (tid == 0) nxt[it & 1] = tn < 0 ? -1 : (gi < my_len ? my_r0 + gi : steal());
+        if (wid == 0) {
+            tile_ticket_wait(gi);
+            if (tid == 0) nxt[it & 1] = tn < 0 ? -1 : ((int)gi < my_len ? my_r0 + (int)gi : steal());
+        }
         t = tn;
         DWPW_STAMP(5)
     }
