@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
         long long* o = reinterpret_cast<long long*>(p.slabs) + ((size_t)blockIdx.x * 4 + wid) * 8;
         for (int i = 0; i < 6; ++i) o[i] = fph[i];
         o[6] = fnt;
-        o[7] = (__builtin_readcyclecounter() - fclk0) * 1000 / ((long long)__builtin_amdgcn_s_memrealtime() - frt0 + 1);   // cycles per 10 us -> MHz / 100 ... = MHz x 10
+        o[7] = (__builtin_readcyclecounter() - fclk0) * 1000 / ((long long)__builtin_amdgcn_s_memrealtime() - frt0 + 1);   // shader cycles per 100 MHz tick x 1000 = MHz x 10
     }
 #endif
 }
@@ -678,30 +678,6 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
 // compiler's wait for the prefetched registers becomes the exact `vmcnt(stores + later loads)` instead of vmcnt(0): the ISA showed
 // vmcnt(21)..(9) as intended, the layers ran no faster and the 16-channel layers slower.
 // C % 8 == 0 (CQ = C / 4 even), Cout % 4 == 0, Cout <= 32 * TN.
-// A returning atomic add whose result is NOT waited for at the issue: HIP's atomicAdd goes through the compiler's wave-level atomic
-// optimiser (reduce, one lane adds, readfirstlane broadcast) and that broadcast puts `s_waitcnt vmcnt(0)` right behind the instruction —
-// 1-3 us of the issuing wave per tile, and the other waves of the workgroup wait for it at the next barrier (measured: 13 k -> 23 k
-// cycles per tile).  Here lane 0 of the calling wave issues the instruction (EXEC narrowed inside the asm block, wave-uniform caller),
-// the result lands in `dst` some time later, and tile_ticket_wait() — the ONLY place `dst` may be read after — drains the counter.
-__device__ __forceinline__ void tile_ticket_issue(unsigned& dst, int* counter) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long saved;
-    const unsigned long long addr = (unsigned long long)counter;
-    const unsigned one = 1u;
-    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
-                 : "+v"(dst), "=&s"(saved) : "v"(addr), "v"(one) : "memory");
-#else
-    (void)dst; (void)counter;
-#endif
-}
-__device__ __forceinline__ void tile_ticket_wait(unsigned& dst) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory");
-#else
-    (void)dst;
-#endif
-}
-
 template <int CQ, int TN, int OCC>
 __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_total) {
     static_assert(CQ % 2 == 0, "whole 8-channel MFMA steps");
@@ -713,7 +689,6 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
     v4f* const dwl = halo + DP_HALO * PQ;                                  // [10][CQ]: 9 taps + bias
     v4f* const Wl = dwl + 10 * CQ;                                         // [STEPS][2][Cout]: A fragments (n = row, 4 k of half h)
     float* const pwb = reinterpret_cast<float*>(Wl + STEPS * 2 * p.Cout);  // [32 * TN] pointwise bias (zero behind Cout)
-    int* const nxt = reinterpret_cast<int*>(pwb + 32 * TN);                // [2] tile of the iteration after next (see the tile loop)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -741,25 +716,12 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) wrow[jn] = h * Cout + min(32 * jn + r, Cout - 1);   // rows >= Cout: any valid address (their columns are never stored)
 
-    // ---- tiles: XCD x owns a contiguous run (neighbouring tiles share halo rows in that XCD's L2), DEALT DYNAMICALLY: a workgroup takes
-    // the next tile of its XCD's run from an atomic counter, and from the other XCDs' runs once its own is empty.  With the static deal
-    // (tile t, t + wgs, ...) the phase stamps showed the slowest wave of a launch 12-33 % above the mean (CUs and XCDs do not run at one
-    // speed) and the kernel ends with the slowest.  The counter is read two tiles ahead by one thread (the atomic is issued before the
-    // K loop, its result parked in LDS after it), so nobody waits for it.
-    const int xcd = blockIdx.x & 7;
+    // ---- tiles: XCD x owns a contiguous run, its workgroups walk it side by side
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, wgs = gridDim.x >> 3;       // (gridDim.x is a multiple of 8)
     const int q8 = tiles_total >> 3, r8 = tiles_total & 7;
+    const int run0 = xcd * q8 + min(xcd, r8), run1 = run0 + q8 + (xcd < r8 ? 1 : 0);
     const int per_img = tiles_x * tiles_y;
-    int* const ctr = p.tile_ctr;                                           // [8], zero at launch
-    const int my_r0 = xcd * q8 + min(xcd, r8), my_len = q8 + (xcd < r8 ? 1 : 0);
-    auto steal = [&]() -> int {                                           // (thread 0 only) own run empty: the other XCDs' runs, nearest first
-        for (int kx = 1; kx < 8; ++kx) {
-            const int x = (xcd + kx) & 7;
-            const int i = atomicAdd(ctr + x, 1);
-            if (i < q8 + (x < r8 ? 1 : 0)) return x * q8 + min(x, r8) + i;
-        }
-        return -1;
-    };
-    auto take = [&]() -> int { const int i = atomicAdd(ctr + xcd, 1); return i < my_len ? my_r0 + i : steal(); };
+
     // halo of tile t: global -> registers (issued, not waited for).  Per thread and item the byte offset relative to the tile's halo
     // origin is tile-invariant (voff); per tile: one add each, and on tiles that touch the left / right border a select.
     v4f pf[NPF];
@@ -792,10 +754,9 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 #pragma unroll
         for (int k = 0; k < NPF; ++k) pf[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo[k], 0, 0));
     };
-    if (tid == 0) { const int a0 = take(); nxt[0] = a0; nxt[1] = a0 >= 0 ? take() : -1; }
-    front_barrier();                                                        // dwl / Wl / pwb / nxt written
-    int t = nxt[0], tn = nxt[1];
-    if (t >= 0) prefetch(t);
+    int t = run0 + wg;
+    if (t < run1) prefetch(t);
+    front_barrier();                                                        // dwl / Wl / pwb written by all waves
 #ifdef FACEHIP_DWPW_PROF
     long long ph[6] = {0, 0, 0, 0, 0, 0}; long long st0; int ntiles = 0;
     const long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
@@ -803,7 +764,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 #else
 #define DWPW_STAMP(i)
 #endif
-    for (int it = 0; t >= 0; ++it) {
+    for (; t < run1; t += wgs) {
         const int n = t / per_img, rem = t - n * per_img;
         const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
         const int ty0 = tyi * DP_TH, tx0 = txi * DP_TW;
@@ -811,7 +772,6 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
         st0 = __builtin_readcyclecounter(); ++ntiles;
 #endif
         front_barrier();                                                    // every wave is done reading the previous tile's halo
-        if (it > 0) tn = nxt[(it + 1) & 1];                                 // (thread 0 parked it there at the end of the previous iteration)
         DWPW_STAMP(0)
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
@@ -819,9 +779,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
             if (i < DP_HALO * CQ) halo[i + i / CQ] = pf[k];              // pixel pitch PQ = CQ + 1
         }
         DWPW_STAMP(1)
-        if (tn >= 0) prefetch(tn);
-        unsigned gi = 0;
-        if (wid == 0 && tn >= 0) tile_ticket_issue(gi, ctr + xcd);          // the tile after next: issued now (lane 0), looked at after the K loop
+        if (t + wgs < run1) prefetch(t + wgs);
         DWPW_STAMP(2)
         front_barrier();                                                    // halo complete
         DWPW_STAMP(3)
@@ -895,11 +853,6 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
                     *reinterpret_cast<v4f*>(orow + co) = v;
                 }
         }
-        if (wid == 0) {
-            tile_ticket_wait(gi);
-            if (tid == 0) nxt[it & 1] = tn < 0 ? -1 : ((int)gi < my_len ? my_r0 + (int)gi : steal());
-        }
-        t = tn;
         DWPW_STAMP(5)
     }
 #ifdef FACEHIP_DWPW_PROF
@@ -919,7 +872,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 // dwpw_kernel (lane = 16-byte channel column, 4 lanes per 64-byte pixel) keeps them coalesced and stays.
 
 static size_t dwpw_reg_lds(int CQ, int Cout, int TN) {
-    return ((size_t)DP_HALO * (CQ + 1) + 10 * CQ + (size_t)(CQ / 2) * 2 * Cout) * 16 + (size_t)32 * TN * 4 + 16;
+    return ((size_t)DP_HALO * (CQ + 1) + 10 * CQ + (size_t)(CQ / 2) * 2 * Cout) * 16 + (size_t)32 * TN * 4;
 }
 static bool dwpw_reg_enabled() {
     static int v = -1;
@@ -943,7 +896,7 @@ static void launch_dwpw_reg_cfg(const ConvArgs& a, hipStream_t s) {
 }
 // true = launched.  Instantiated for SCRFD-500M's stride-1 blocks (C = 16 / 40 / 64 / 72) with any Cout <= 96.
 static bool launch_dwpw_reg(const ConvArgs& a, hipStream_t s) {
-    if (!dwpw_reg_enabled() || a.dw_stride != 1 || a.u8_src || a.Cout % 4 || a.Cout > 96 || a.H != a.Ho || a.W != a.Wo || !a.tile_ctr) return false;
+    if (!dwpw_reg_enabled() || a.dw_stride != 1 || a.u8_src || a.Cout % 4 || a.Cout > 96 || a.H != a.Ho || a.W != a.Wo) return false;
     if (a.act != (int)Act::NONE && a.act != (int)Act::RELU) return false;
     if ((long)a.H * a.W * a.Cin * 4 >= (1L << 31)) return false;            // one image must fit a 32-bit buffer range
     const int tn = (a.Cout + 31) / 32;
@@ -973,8 +926,16 @@ static void launch_front(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.Wo + DP_TW - 1) / DP_TW, tiles_y = (a.Ho + DP_TH - 1) / DP_TH;
     const int tiles_total = a.B * tiles_y * tiles_x;
     const int cus = a.cus > 0 ? a.cus : conv_num_cus();
-    const int grid = std::min((tiles_total + 7) / 8 * 8, cus * 4);        // persistent: 4 workgroups per CU, a multiple of 8 (XCDs)
-    const dim3 g3((unsigned)std::max(8, grid / 8 * 8));
+    int grid = std::min((tiles_total + 7) / 8 * 8, cus * 4);              // persistent: 4 workgroups per CU, a multiple of 8 (XCDs)
+    grid = std::max(8, grid / 8 * 8);
+    // A workgroup walks tiles t, t + grid / 8, ...: with a stride that shares a factor with the tile grid (128 and 20 columns: period 5)
+    // some workgroups meet a border COLUMN in every fifth tile and others never — border tiles run the per-byte pass and cost ~2x, and the
+    // phase stamps showed the slowest wave 33 % above the mean.  A stride coprime with tiles_x and tiles_y gives everyone the same mix.
+    auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+    int wgs = grid / 8;
+    while (wgs > 1 && (gcd(wgs, tiles_x) != 1 || gcd(wgs, tiles_y) != 1)) --wgs;
+    if (wgs * 8 * 10 >= grid * 9) grid = wgs * 8;                           // (only if it costs < 10 % of the workgroups)
+    const dim3 g3((unsigned)grid);
     if (a.u8_step % 4 == 0) hipLaunchKernelGGL(front_kernel<true>, g3, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_total);
     else hipLaunchKernelGGL(front_kernel<false>, g3, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_total);
 }

@@ -138,7 +138,6 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
         const POp& op = plan_.ops[i];
         DevOp& d = dev_[i];
         if (op.kind == OpKind::DWPW) {
-            has_dwpw_ = true;
             d.dww = push(op.dw_weight.data(), op.dw_weight.size());
             d.dwb = push(op.dw_bias.data(), op.dw_bias.size());
         }
@@ -315,7 +314,6 @@ void Net::reserve(int max_batch) {
 void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int batch, hipStream_t s) {
     if (batch <= 0) return;
     if (batch > cap_) throw std::runtime_error("Net::run_u8: batch exceeds reserved capacity");
-    zero_tile_counters(s);
     if (stem_ok_ && fuse_stem && front_ok_ && fuse_front) {
         // stem conv -> depthwise 3x3 -> pointwise 1x1 in ONE kernel: the stem's 16-channel map (the largest tensor of SCRFD) is never written
         const POp& st = plan_.ops[0];
@@ -334,11 +332,10 @@ void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int st
         a.u8_stride = st.stride; a.stem_act = (int)st.act; a.stem_wf = P + d0.wf; a.stem_bf = P + d0.bf;
         a.stem_wfrag = reinterpret_cast<const unsigned*>(P + d0.wfr);
         a.cus = cus;
-        a.tile_ctr = tile_ctr_.as<int>() + 8 * 1;                            // (the counter set of op 1)
         a.t_flops = 2.0 * (st.macs + op.macs) * batch;
         a.t_bytes = ((double)srcH * srcW * 3 + (double)op.Ho * op.Wo * op.Cout * 4) * batch;        // u8 frame in, pointwise map out
         launch_dwpw(a, s);
-        run(batch, s, 2, /*counters_zeroed=*/true);
+        run(batch, s, 2);
         return;
     }
     if (stem_ok_ && fuse_stem) {
@@ -352,19 +349,11 @@ void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int st
                             op.out2 >= 0 && !d.bn_fold_dst ? tensor_ptr(op.out2) : nullptr, d.has_aff ? P + d.s2 : nullptr,
                             d.has_aff ? P + d.t2 : nullptr, s, d.wfr ? reinterpret_cast<const unsigned*>(P + d.wfr) : nullptr);
         timer.end(s, 5, 2.0 * op.macs * batch, op.bytes * batch);
-        run(batch, s, 1, true);
+        run(batch, s, 1);
         return;
     }
     launch_det_preprocess(src, img_stride, srcH, srcW, step, batch, plan_.inH, plan_.inW, srcH, srcW, input(), s);
-    run(batch, s, 0, true);
-}
-
-// The persistent depthwise kernels deal their tiles from atomic counters (8 per launch, one per XCD): one stream-ordered memset per
-// network pass covers every launch of the pass (set i & 63 belongs to op i).
-void Net::zero_tile_counters(hipStream_t s) {
-    if (!has_dwpw_) return;
-    if (!tile_ctr_.p) tile_ctr_.ensure(64 * 8 * sizeof(int));
-    FH_HIP(hipMemsetAsync(tile_ctr_.p, 0, 64 * 8 * sizeof(int), s));
+    run(batch, s, 0);
 }
 
 int Net::set_bf16x2(bool on, hipStream_t s) {
@@ -381,9 +370,8 @@ int Net::set_bf16x2(bool on, hipStream_t s) {
     return on ? layers : 0;
 }
 
-void Net::run(int batch, hipStream_t s, int first_op, bool counters_zeroed) {
+void Net::run(int batch, hipStream_t s, int first_op) {
     if (batch <= 0) return;
-    if (!counters_zeroed) zero_tile_counters(s);
     if (sk_gen_ != conv_error_generation() && partial_.p) {   // a stream-K hand-off timed out somewhere since: late helper arrivals may have
         conv_workspace_reset_async(partial_.as<float>(), s);  // left counters non-zero — re-zero them, stream-ordered, before the next launch
         sk_gen_ = conv_error_generation();
@@ -490,7 +478,6 @@ void Net::run(int batch, hipStream_t s, int first_op, bool counters_zeroed) {
                 a.ks = 1; a.stride = 1; a.pad = 0; a.Kpad = d.Kpad; a.act = (int)op.act;
                 a.t_flops = 2.0 * op.macs * batch; a.t_bytes = op.bytes * batch;
                 a.slabs = partial_.as<float>();                             // (diagnostic builds park their phase stamps there)
-                a.tile_ctr = tile_ctr_.as<int>() + 8 * (i & 63);
                 launch_dwpw(a, s);
                 break;
             }

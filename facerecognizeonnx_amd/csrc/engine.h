@@ -33,8 +33,7 @@ class Net {
     void reserve(int max_batch);                          // arena + split-K slabs for this batch
     float* input() const { return arena_.as<float>() + plan_.tensors[plan_.input].offset * (size_t)cap_; }
     float* output(int i) const { return tensor_ptr(plan_.outputs[i].tensor); }
-    void run(int batch, hipStream_t s, int first_op = 0, bool counters_zeroed = false);
-    void zero_tile_counters(hipStream_t s);
+    void run(int batch, hipStream_t s, int first_op = 0);
     // preprocess (+ first conv when it can be fused) straight from BGR u8 images, then the rest of the graph.
     // srcH x srcW = pasted image (<= net input; the remainder is the zero letterbox canvas)
     void run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int batch, hipStream_t s);
@@ -92,12 +91,10 @@ class Net {
     Plan plan_;
     std::vector<DevOp> dev_;
     DevBuf params_, arena_, partial_, wino_v_, wino_m_, w36_bf_;
-    DevBuf tile_ctr_;                                         // 64 sets of 8 tile counters for the persistent depthwise kernels, zeroed once per run
     bool bf16x2_ = false;
     size_t wino_maxc_ = 0;
     size_t wino_elems_ = 0;                                   // per image: 36 * tiles * max(Cin, Cout) of the largest Winograd op
     int cap_ = 0;
-    bool has_dwpw_ = false;                                   // the plan has depthwise -> pointwise ops (their kernels need zeroed tile counters)
     unsigned sk_gen_ = 0;                                     // conv_error_generation() this Net's hand-off counters were last zeroed under
     bool stem_ok_ = false;
     bool front_ok_ = false;                                   // ops 0 + 1 = stem conv (16 channels) -> DW+PW: one kernel

@@ -95,7 +95,6 @@ struct ConvArgs {
     unsigned* sk_err;
     unsigned sk_timeout;
     int sk_test_drop;
-    int* tile_ctr;          // persistent depthwise kernels (dwpw_reg_kernel, front_kernel): 8 tile counters (one per XCD), ZERO at launch
     int tile0;              // filled in by launch_conv: first tile conv_igemm_kernel computes (the tiles before it ran in conv_tall_kernel)
 };
 
