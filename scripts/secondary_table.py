@@ -2,14 +2,15 @@
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-rows = [("headline", "headline: 128 frames 640x640, detect+align+embed, F=1", "(default)"),
+rows = [("headline", "headline: 128 frames 640x640, detect+align+embed, F=1 (streaming form)", "(default)"),
         ("c2_embed", "C2: ArcFace w600k_r50, 256 pre-aligned crops", "`--workload embed`"),
         ("c3_detect", "C3: SCRFD det_500m + decode + NMS, 128 frames", "`--workload detect`"),
         ("f4", "headline with 4 faces per frame", "`--faces-per-frame 4`"),
         ("c4_gallery", "C4: 64 frames end-to-end + top-16 of a 1 M x 512 gallery", "`--gallery 1000000 --frames 64`"),
         ("c4_match", "C4 match stage alone: 64 queries vs 1 M x 512 gallery, top-16 (one scan kernel + list merge)", "`--workload match --gallery 1000000 --queries 64 --topk 16`"),
         ("from_host", "PCIe-inclusive headline (pinned host frames, double-buffered H2D)", "`--from-host`"),
-        ("overlap", "headline, streaming form: detector of batch k+1 on its own stream beside the recogniser of batch k", "`--overlap`"),
+        ("serial", "headline, one batch at a time on one stream (the default streams: detector of batch k+1 beside the recogniser of batch k)", "`--serial`"),
+        ("latency", "batch-1 latency through the blocking C-ABI (`fh_det_detect` + `fh_rec_extract` from host memory, HIP-graph replay)", "`--workload latency`"),
         ("mbf_embed", "MobileFaceNet (w600k_mbf, the buffalo_sc recogniser) instead of w600k_r50: 256 pre-aligned crops", "`--workload embed --recogniser mbf`"),
         ("mbf_e2e", "headline pipeline with MobileFaceNet as the recogniser", "`--recogniser mbf`")]
 out = [f"# Round {tag} — other BASELINE.json configurations (same build as profiles/{tag}_summary.md)", "",

@@ -45,14 +45,19 @@ def short(name):
     return base + (targs if len(targs) < 24 else "")
 
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+def newest(pattern):
+    """gpurun merges every call's output into the same scratch tree: take the latest run, not the first the glob returns."""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
+
+
+stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as f:
     f.write(open(stats).read())
 
 agg = collections.defaultdict(lambda: {"launches": 0, "fetch_kib": 0.0, "write_kib": 0.0})
 for kind, key in (("fetch", "fetch_kib"), ("write", "write_kib")):
-    files = glob.glob(os.path.join(src, kind, "*", "*_counter_collection.csv"))
+    files = newest(os.path.join(src, kind, "*", "*_counter_collection.csv"))
     if not files:
         continue
     seen = collections.Counter()
@@ -85,7 +90,7 @@ bj = os.path.join(src, "bench_under_rocprof.json")
 if os.path.exists(bj):
     bench = open(bj).read().strip()
 with open(os.path.join(dst, f"{tag}_summary.md"), "w") as f:
-    f.write(f"# rocprofv3 summary {tag} — `python3 bench.py --steps 5 --warmup 2` ({workload})\n\n")
+    f.write(f"# rocprofv3 summary {tag} — `python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --serial` ({workload})\n\n")
     f.write("`rocprofv3 --kernel-trace --stats` (all steps of the run: warm-up + timed + instrumented; a profiled run is slower than an un-profiled one):\n\n")
     f.write("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows[:16]:
