@@ -893,27 +893,34 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
     a.tile0 = 0;
     // 3x3 stride-1 layers on maps up to 112 wide: the whole ROUNDS of tiles run in conv_tall_kernel (one LDS image per 32-channel chunk
     // for all nine taps), the remainder below with tile0 = the first tile it did not take
-    if constexpr (BM == 256 && BN == 64)
-    if (tall_enabled() && !grouped && !a.sc_in && a.ks == 3 && a.stride == 1 && a.pad == 1 && (a.Cin & 31) == 0 &&
-        a.H == a.Ho && a.W == a.Wo && a.W <= 112 && a.n_outs == 0 && (a.Cout & 3) == 0 && a.res_mode != (int)ResMode::UP2X && T >= S) {
-        constexpr int RPt = Tile<BM, BN, WM, WN>::RP;
-        const int rows_a = (BM + 2 * a.W + 2 + RPt - 1) / RPt * RPt;
-        const size_t lds = ((size_t)rows_a * 8 + 2 * BN * 8) * sizeof(v4f);
-        int tall_tiles = (T / S) * S;
-        tall_tiles -= tall_tiles % tiles_n;
-        if (lds <= 80 * 1024 && tall_tiles > 0) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tall_kernel<BM, BN, WM, WN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-                attr_set = true;
+    // (256x64: IResNet's stage 1 / 2.  128x32: SCRFD's merged 64 -> 30 head convolutions at B = 128 — 340 -> 330 us on 80x80, 98 -> 91 on
+    // 40x40: a small gain, because with three phase-locked workgroups per CU the image load at the top of each of the two chunks stays
+    // exposed; a three-deep weight ring (two taps ahead, barrier with vmcnt(1)) changed nothing: 306 against 307 us)
+    if constexpr ((BM == 256 && BN == 64) || (BM == 128 && BN == 32)) {
+        constexpr int TOCC = BM == 256 ? 2 : 3;                             // resident workgroups per CU of the tall form (LDS)
+        const int St = (a.cus > 0 ? a.cus : num_cus()) * TOCC;
+        if (tall_enabled() && !grouped && !a.sc_in && a.ks == 3 && a.stride == 1 && a.pad == 1 && (a.Cin & 31) == 0 &&
+            a.H == a.Ho && a.W == a.Wo && a.W <= 112 && (BN == 32 ? a.n_outs > 0 || (a.Cout & 3) == 0 : a.n_outs == 0 && (a.Cout & 3) == 0) &&
+            a.res_mode != (int)ResMode::UP2X && T >= St) {
+            constexpr int RPt = Tile<BM, BN, WM, WN>::RP;
+            const int rows_a = (BM + 2 * a.W + 2 + RPt - 1) / RPt * RPt;
+            const size_t lds = ((size_t)rows_a * 8 + 2 * BN * 8) * sizeof(v4f);
+            int tall_tiles = (T / St) * St;
+            tall_tiles -= tall_tiles % tiles_n;
+            if (lds <= (size_t)(160 / TOCC) * 1024 && tall_tiles > 0) {
+                static bool attr_set = false;
+                if (!attr_set) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tall_kernel<BM, BN, WM, WN, TOCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+                    attr_set = true;
+                }
+                KernelTimer& tt = KernelTimer::get();
+                tt.begin(s);
+                hipLaunchKernelGGL((conv_tall_kernel<BM, BN, WM, WN, TOCC>), dim3((unsigned)tall_tiles), dim3(WM * WN * 64), lds, s, a, tiles_n, rows_a);
+                tt.end(s, 10, a.t_flops * ((double)tall_tiles / T), a.t_bytes * ((double)tall_tiles / T));
+                a.t_flops *= (double)(T - tall_tiles) / T; a.t_bytes *= (double)(T - tall_tiles) / T;
+                a.tile0 = tall_tiles;
+                if (tall_tiles == T) return;
             }
-            KernelTimer& tt = KernelTimer::get();
-            tt.begin(s);
-            hipLaunchKernelGGL((conv_tall_kernel<BM, BN, WM, WN, OCC>), dim3((unsigned)tall_tiles), dim3(WM * WN * 64), lds, s, a, tiles_n, rows_a);
-            tt.end(s, 10, a.t_flops * ((double)tall_tiles / T), a.t_bytes * ((double)tall_tiles / T));
-            a.t_flops *= (double)(T - tall_tiles) / T; a.t_bytes *= (double)(T - tall_tiles) / T;
-            a.tile0 = tall_tiles;
-            if (tall_tiles == T) return;
         }
     }
     return launch_cfg_tail<BM, BN, WM, WN, OCC>(a, resident_per_cu, cfg_tag, s, T - a.tile0, tiles_n, S);

@@ -57,6 +57,8 @@ CONV_CASES = [
     # taps masked per lane: ragged map, image boundaries inside tiles), the remainder in conv_igemm_kernel with tile0 > 0 (+ its fix-up)
     (66, 40, 52, 32, 48, 3, 1, 1),
     (35, 61, 63, 64, 64, 3, 1, 1),
+    # the 128x32 instantiation (SCRFD's merged head convolutions take it at B = 128): 811 tiles, 768 of them in conv_tall_kernel
+    (27, 61, 63, 32, 32, 3, 1, 2),
 ]
 
 
