@@ -751,8 +751,9 @@ int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi, const float* d_
         const size_t tiles = (size_t)batch * ((h + 3) / 4) * ((w + 3) / 4);
         fh::DevBuf dU, dV, dM;
         dU.ensure(u36.size() * sizeof(float));
-        dV.ensure(36 * (size_t)fh::wino_rows((long)tiles) * cin * sizeof(float));
-        dM.ensure(36 * (size_t)fh::wino_rows((long)tiles) * cout * sizeof(float));
+        // (+ 100 x 128 rows: the mixed F(4x4) / F(2x2) tiling pads each of its up to 100 planes to whole 128-row GEMM tiles)
+        dV.ensure((36 * (size_t)fh::wino_rows((long)tiles) + 100 * 128) * cin * sizeof(float));
+        dM.ensure((36 * (size_t)fh::wino_rows((long)tiles) + 100 * 128) * cout * sizeof(float));
         FH_HIP(hipMemcpy(dU.p, u36.data(), u36.size() * sizeof(float), hipMemcpyHostToDevice));
         static fh::DevBuf slabs;
         static unsigned slabs_gen = 0;

@@ -439,28 +439,39 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                     // (IResNet-50, B = 128: 12.75 ms against 14.72 ms)
                     const int wcfg = force_cfg >= 0 ? force_cfg : 2;
                     const bool bf2 = bf16x2_ && d.bf2 && force_cfg < 0;
+                    // maps of side 4 k + 2 (14x14): the mixed F(4x4) / F(2x2) tiling (winograd.hip, WinoPlanes) — its own V / M layout, so
+                    // the producer of V and the consumer must agree: the decision depends on the map and the batch only
+                    WinoPlanes pl;
+                    const bool mix = wcfg == 2 && wino_mix_layout(batch, op.H, op.W, op.Cin, op.Cout, &pl);
                     if (!v_ready) {                                     // (else the previous layer's fused transform already wrote V)
                         const float* in_s = nullptr; const float* in_t = nullptr;
                         if (d.aff_src >= 0) {
                             a.in = tensor_ptr(plan_.ops[d.aff_src].out);
                             in_s = P + dev_[d.aff_src].s2; in_t = P + dev_[d.aff_src].t2;
                         }
-                        launch_wino_input(a, wino_v_.as<float>(), in_s, in_t, bf2, s);
+                        if (mix) launch_wino_mix(a, pl, nullptr, wino_v_.as<float>(), 0, in_s, in_t, bf2, s);
+                        else launch_wino_input(a, wino_v_.as<float>(), in_s, in_t, bf2, s);
                     }
-                    launch_wino_gemm(a, bf2 ? w36_bf_.as<float>() + d.w36p : P + d.w36, wino_v_.as<float>(), wino_m_.as<float>(), wcfg, bf2, s);
+                    launch_wino_gemm(a, bf2 ? w36_bf_.as<float>() + d.w36p : P + d.w36, wino_v_.as<float>(), wino_m_.as<float>(), wcfg, bf2, s,
+                                     mix ? &pl : nullptr);
                     v_ready = false;
                     if (d.fuse_next && fuse_wino && i + 1 < plan_.ops.size()) {
                         const POp& nx = plan_.ops[i + 1];
                         const bool next_wino = dev_[i + 1].wino && (long)batch * ((nx.H + 3) / 4) * ((nx.W + 3) / 4) >= kWinoMinTiles;
-                        if (next_wino) {
+                        const bool next_mix = next_wino && wcfg == 2 && wino_mix_layout(batch, nx.H, nx.W, nx.Cin, nx.Cout, nullptr);
+                        if (next_wino && mix == next_mix) {
                             ConvArgs e = a;
                             if (!d.fuse_keep_out1) e.out1 = nullptr;
-                            launch_wino_fused(e, wino_m_.as<float>(), wino_v_.as<float>(), d.fuse_feed_aff ? 1 : 0,
-                                              bf16x2_ && dev_[i + 1].bf2 && force_cfg < 0, s);
+                            const bool pack_next = bf16x2_ && dev_[i + 1].bf2 && force_cfg < 0;
+                            if (mix) launch_wino_mix(e, pl, wino_m_.as<float>(), wino_v_.as<float>(), d.fuse_feed_aff ? 1 : 0, nullptr, nullptr, pack_next, s);
+                            else launch_wino_fused(e, wino_m_.as<float>(), wino_v_.as<float>(), d.fuse_feed_aff ? 1 : 0, pack_next, s);
                             v_ready = true;
                         }
                     }
-                    if (!v_ready) launch_wino_output(a, wino_m_.as<float>(), s);
+                    if (!v_ready) {
+                        if (mix) launch_wino_mix(a, pl, wino_m_.as<float>(), nullptr, 0, nullptr, nullptr, false, s);
+                        else launch_wino_output(a, wino_m_.as<float>(), s);
+                    }
                     tag = 7;
                     break;
                 }

@@ -130,13 +130,39 @@ void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float*
                           hipStream_t s);
 // the three stages separately, and stage 3 of one convolution fused with stage 1 of the next (same map, C = Cout = next Cin)
 // pack / bf16x2 / pack_next: the opt-in split-bf16 operand format (V and U as (hi, mid) bf16 pairs in 32-bit words, see winograd.hip)
+struct WinoPlanes;
 void launch_wino_input(const ConvArgs& a, float* V, const float* in_scale, const float* in_shift, bool pack, hipStream_t s);
-void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, float* M, int cfg, bool bf16x2, hipStream_t s);
+void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, float* M, int cfg, bool bf16x2, hipStream_t s,
+                      const WinoPlanes* mix = nullptr);   // mix: V / M in the mixed-tiling layout (lean kernel only)
 bool wino_gemm_ok_bf16x2(int Cin, int Cout);
 void launch_wino_output(const ConvArgs& a, const float* M, hipStream_t s);
 bool wino_can_fuse(int H, int W, int C, bool touches_memory);
 void launch_wino_fused(const ConvArgs& a, const float* M, float* Vnext, int feed_aff, bool pack_next, hipStream_t s);
 void launch_pack_bf16x2(const float* in, float* out, long n, hipStream_t s);      // fp32 -> split-bf16 words, n % 4 == 0
+// Mixed F(4x4) / F(2x2) tiling (round 3) for maps whose side is 4 k + 2 or 4 k + 1 (IResNet's 14x14): the last tile row / column is an
+// F(2x2, 3x3) tile instead of an F(4x4) tile hanging over the border — 484 instead of 576 GEMM rows per 14x14 image.  Tiles fall into
+// four classes (rows F4 | F2) x (columns F4 | F2) with 36 / 24 / 24 / 16 frequency planes; the F(2) interpolation points {0, +-1, inf}
+// are a subset of F(4)'s, so the planes multiply the SAME 36 weight matrices (plane (i, j) of an F(2) direction uses frequency
+// {0, 1, 2, 5}[i] with the row scales {4, -3, -3, 1} folded into the input transform).
+struct WinoPlanes {
+    int e[4];                // first 128-row GEMM tile of class c (classes stored one after the other, plane-major inside a class)
+    int t[4];                // 128-row GEMM tiles per plane
+    int nfc[4];              // frequencies along a patch row: 6 (F4 columns) or 4 (F2 columns)
+    int f2[4];               // bit 0: columns are F(2), bit 1: rows are F(2)
+    int n[4];                // tiles per image
+    int rows[4];             // rows per plane (B * n rounded up to 128)
+    int base[4];             // first row of the class's first plane
+    int total_tiles;         // 128-row GEMM tiles over all planes
+    int planes;              // 36 + 24 + 24 + 16 (classes with n = 0 contribute none)
+};
+// layout of the mixed tiling for B images of H x W; false: this map / batch keeps the uniform tiling
+bool wino_mix_layout(int B, int H, int W, int Cin, int Cout, WinoPlanes* out);
+// one kernel for the three transform roles of a mixed-tiling convolution `a` (whole images x 64 channels per workgroup):
+//   M != null: Y = A^T M A of convolution `a` (+bias, activation, residual; out1 / out2 written when non-null), else the image comes from
+//              a.in (per-channel affine in_scale / in_shift on in-image pixels when non-null);
+//   Vnext != null: V = B^T d B for the next convolution (= `a` itself when M is null) from that image (feed_aff: through a.s2 / a.t2).
+void launch_wino_mix(const ConvArgs& a, const WinoPlanes& pl, const float* M, float* Vnext, int feed_aff, const float* in_scale,
+                     const float* in_shift, bool pack_next, hipStream_t s);
 void wino_filter_transform(const double g[9], double u[36]);
 long wino_rows(long tiles);                  // rows per frequency plane of the V / M workspaces (tiles rounded up to 256)     // host: G g G^T of one 3x3 filter
 int conv_wt_rows(int Cout);                   // packed weight rows (Cout rounded up to 128)

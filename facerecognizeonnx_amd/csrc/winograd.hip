@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "kernels.h"
@@ -327,9 +328,20 @@ __device__ __forceinline__ void wino_dma16(const float* src, v4f* dst) {
 #endif
 }
 
+// weight matrix (frequency 6 i + j of the F(4x4) set) of the plane GEMM tile `tile_m` belongs to — see WinoPlanes (kernels.h)
+__device__ __forceinline__ int wino_plane_freq(const WinoPlanes& pl, const int tile_m) {
+    const int c = tile_m >= pl.e[3] ? 3 : tile_m >= pl.e[2] ? 2 : tile_m >= pl.e[1] ? 1 : 0;
+    const int pln = (tile_m - pl.e[c]) / pl.t[c];
+    const int nfc = pl.nfc[c], f2 = pl.f2[c];
+    int i = pln / nfc, j = pln - i * nfc;
+    if ((f2 & 2) && i == 3) i = 5;                            // F(2) points {0, 1, -1, inf} = F(4) frequencies {0, 1, 2, 5}
+    if ((f2 & 1) && j == 3) j = 5;
+    return 6 * i + j;
+}
+
 template <int BN, int OCC>
 __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M,
-                                                            const int K, const int N, const int rows_per_group, const long wt_gs,
+                                                            const int K, const int N, const WinoPlanes pl, const long wt_gs,
                                                             const int tiles_n, const int chunks) {
     constexpr int BM = 128, TN = BN / 32, AL = BM / 32, BL = BN / 32;
     __shared__ v4f lds[2][(BM + BN) * 8];
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __rest
     const int tile = x * q + min(x, r8) + (blockIdx.x >> 3);
     const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const float* Ug = U + (size_t)(m0 / rows_per_group) * wt_gs;
+    const float* Ug = U + (size_t)wino_plane_freq(pl, tile_m) * wt_gs;
 
     const int lrow = tid >> 3;
     const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);              // source k-column of this lane (swizzle on the source side)
@@ -400,7 +412,7 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __rest
 // by the L2 -> LDS stream it shares with the f32 form.
 template <int BN, int OCC>
 __global__ __launch_bounds__(256, OCC) void wino_gemm_bf16x2_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M,
-                                                                   const int K, const int N, const int rows_per_group, const long wt_gs,
+                                                                   const int K, const int N, const WinoPlanes pl, const long wt_gs,
                                                                    const int tiles_n, const int chunks) {
     constexpr int BM = 128, TN = BN / 32, AL = BM / 32, BL = BN / 32;
     __shared__ v4f lds[2][(BM + BN) * 8];
@@ -411,7 +423,7 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_bf16x2_kernel(const float*
     const int tile = x * q + min(x, r8) + (blockIdx.x >> 3);
     const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const float* Ug = U + (size_t)(m0 / rows_per_group) * wt_gs;
+    const float* Ug = U + (size_t)wino_plane_freq(pl, tile_m) * wt_gs;
     const int lrow = tid >> 3;
     const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);
     const float* a_src = V + (size_t)(m0 + lrow) * K + lqs * 4;
@@ -511,7 +523,44 @@ void launch_wino_input(const ConvArgs& a, float* V, const float* in_scale, const
 // bf16x2: V and wt36 hold split-bf16 words (wino_gemm_ok_bf16x2 says whether this layer's GEMM has that form)
 bool wino_gemm_ok_bf16x2(int Cin, int Cout) { return Cout % 64 == 0 && Cin % 32 == 0; }
 
-void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, float* M, int cfg, bool bf16x2, hipStream_t s) {
+static int wino_mix_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FACEHIP_WINO_MIX"); v = e ? atoi(e) : 1; }          // (0 = uniform F(4x4) tiling everywhere: A / B timing)
+    return v;
+}
+
+static bool wino_bn128(bool mixed) {                           // tuning hook: 1 = 128x128 GEMM tiles for the mixed layout, 2 = everywhere
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FACEHIP_WINO_BN128"); v = e ? atoi(e) : 0; }
+    return v == 2 || (v == 1 && mixed);
+}
+
+bool wino_mix_layout(int B, int H, int W, int Cin, int Cout, WinoPlanes* out) {
+    const int TY = (H + 3) / 4, TX = (W + 3) / 4;
+    const int my = (H & 3) == 1 || (H & 3) == 2, mx = (W & 3) == 1 || (W & 3) == 2;
+    // the transform kernel takes one image x 64 channels per workgroup with 16 tiles x 16 float4 columns on its 256 threads; small batches
+    // would pad the thin classes' planes (B tiles per plane for the corner class) to mostly empty 128-row GEMM tiles
+    if (!wino_mix_enabled() || !(my || mx) || TY * TX != 16 || Cin % 64 || Cout % 64 || B < 64) return false;
+    if ((size_t)H * W * 16 * sizeof(v4f) > 64 * 1024) return false;
+    WinoPlanes pl{};
+    const int n[4] = {(TY - my) * (TX - mx), (TY - my) * mx, my * (TX - mx), my * mx};
+    int tile = 0, row = 0, planes = 0;
+    for (int c = 0; c < 4; ++c) {
+        const int nfr = (c & 2) ? 4 : 6, nfc = (c & 1) ? 4 : 6;
+        pl.n[c] = n[c]; pl.nfc[c] = nfc; pl.f2[c] = c;
+        pl.rows[c] = (B * n[c] + 127) / 128 * 128;
+        pl.t[c] = pl.rows[c] / 128;
+        pl.e[c] = tile; pl.base[c] = row;
+        tile += nfr * nfc * pl.t[c]; row += nfr * nfc * pl.rows[c];
+        if (n[c]) planes += nfr * nfc;
+    }
+    if ((long)row * std::max(Cin, Cout) * 4 >= (1L << 31)) return false;              // (the transform kernel addresses V / M through 32-bit buffer offsets)
+    pl.total_tiles = tile; pl.planes = planes;
+    if (out) *out = pl;
+    return true;
+}
+
+void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, float* M, int cfg, bool bf16x2, hipStream_t s, const WinoPlanes* mix) {
     const int TY = (a.H + 3) / 4, TX = (a.W + 3) / 4;
     const long NT = (long)a.B * TY * TX;
     if (NT <= 0) return;
@@ -525,22 +574,36 @@ void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, floa
     // booked on the GEMM: the FLOPs it EXECUTES on real rows (physical matrix-core utilisation) and, in the bytes slot of the
     // timer, the direct-form FLOPs of the convolution it stands for (the algorithmic figure bench.py quotes beside it)
     g.t_flops = 2.0 * 36.0 * (double)NT * a.Cin * a.Cout; g.t_bytes = a.t_flops;
+    WinoPlanes pl{};
+    if (mix) {
+        if (!(a.Cout % 32 == 0 && cfg == 2)) throw std::runtime_error("winograd: the mixed tiling runs on the lean GEMM kernel only");
+        pl = *mix;
+        double real_rows = 0;
+        for (int c = 0; c < 4; ++c) real_rows += (double)((c & 2) ? 4 : 6) * pl.nfc[c] * a.B * pl.n[c];
+        g.t_flops = 2.0 * real_rows * a.Cin * a.Cout;
+    } else {
+        pl.e[0] = 0; pl.e[1] = pl.e[2] = pl.e[3] = (int)(36 * NTp / 128); pl.t[0] = (int)(NTp / 128); pl.nfc[0] = 6;
+        pl.total_tiles = pl.e[1];
+    }
     if (a.Cout % 32 == 0 && cfg == 2) {
         // the lean kernel: 128 x 64 tiles (IResNet-50 at B = 128 / 256: 9.89 / 19.5 ms; 128 x 32: 9.96 / 19.8; 128 x 128: 10.2 / 19.6)
-        const long rows = 36 * NTp;
+        const long rows = 128L * pl.total_tiles;
         const int chunks = a.Cin / 32;
         const bool wide = a.Cout % 64 == 0;
         timer.begin(s);
         if (bf16x2) {
             if (!wino_gemm_ok_bf16x2(a.Cin, a.Cout)) throw std::runtime_error("winograd: this layer has no split-bf16 GEMM");
             hipLaunchKernelGGL((wino_gemm_bf16x2_kernel<64, 3>), dim3((unsigned)((rows / 128) * (a.Cout / 64))), dim3(256), 0, s, V, wt36, M, a.Cin,
-                               a.Cout, (int)NTp, g.wt_gs, a.Cout / 64, chunks);
-        } else if (wide)
+                               a.Cout, pl, g.wt_gs, a.Cout / 64, chunks);
+        } else if (wide && a.Cout % 128 == 0 && wino_bn128(mix != nullptr))
+            hipLaunchKernelGGL((wino_gemm_kernel<128, 2>), dim3((unsigned)((rows / 128) * (a.Cout / 128))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
+                               pl, g.wt_gs, a.Cout / 128, chunks);
+        else if (wide)
             hipLaunchKernelGGL((wino_gemm_kernel<64, 3>), dim3((unsigned)((rows / 128) * (a.Cout / 64))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
-                               (int)NTp, g.wt_gs, a.Cout / 64, chunks);
+                               pl, g.wt_gs, a.Cout / 64, chunks);
         else
             hipLaunchKernelGGL((wino_gemm_kernel<32, 4>), dim3((unsigned)((rows / 128) * (a.Cout / 32))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
-                               (int)NTp, g.wt_gs, a.Cout / 32, chunks);
+                               pl, g.wt_gs, a.Cout / 32, chunks);
         timer.end(s, 7, g.t_flops, g.t_bytes);
     } else {
         if (bf16x2) throw std::runtime_error("winograd: this layer has no split-bf16 GEMM");
@@ -604,9 +667,191 @@ void launch_wino_fused(const ConvArgs& a, const float* M, float* Vnext, int feed
     timer.end(s, 8, 0.0, 0.0);
 }
 
+// ---- mixed F(4x4) / F(2x2) tiling: the transform kernel (see WinoPlanes in kernels.h) --------------------------------------------------
+// wino_fused_kernel's anatomy (one image x 64 channels per workgroup, thread = (tile, float4 column), LDS image between the two phases)
+// with the tile's class decided per thread: the row direction of a tile is wave-uniform (wave = tile row), the column direction differs
+// between the 16-lane groups of a wave.  Both 1-D transforms are evaluated and selected (the kernel is bound by its V / M traffic, not by
+// the vector ALU); frequencies a class does not have are addressed OUT OF RANGE of the buffer descriptor, so their loads return zero
+// and their stores are dropped by the hardware — no branch, and the 36 loads of a thread stay in flight together.
+// F(2x2,3x3) with the points {0, 1, -1, inf}: B^T rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3), A^T = [1 1 1 0; 0 1 -1 -1]; its G rows are
+// (4, -3, -3, 1) x the rows {0, 1, 2, 5} of F(4x4,3x3)'s G, so with those factors on the B^T rows the planes multiply the F(4x4) weight
+// matrices U[6 i + j] unchanged.
+struct WinoMixArgs {
+    WinoOutArgs o;          // (o.M null: the image comes from `in`)
+    WinoPlanes pl;
+    const float* in; const float* in_s; const float* in_t;
+    float* V;
+    unsigned plane_bytes;   // size of the V / M workspace in this layout (bytes): the buffer descriptors' range
+    int feed_aff, pack;
+};
+
+__device__ __forceinline__ void wino_bt2s(const v4f (&d)[6], v4f (&t)[6]) {
+    t[0] = 4.f * (d[0] - d[2]);
+    t[1] = -3.f * (d[1] + d[2]);
+    t[2] = 3.f * (d[1] - d[2]);
+    t[3] = d[1] - d[3];
+    t[4] = v4f{0.f, 0.f, 0.f, 0.f};
+    t[5] = t[4];
+}
+
+__global__ __launch_bounds__(256, 2) void wino_mix_kernel(const WinoMixArgs a) {
+    const WinoOutArgs& p = a.o;
+    extern __shared__ v4f act[];                               // [H*W][16 float4]
+    const int C = p.C, HW = p.H * p.W;
+    const int tid = threadIdx.x, c4l = tid & 15, tile = tid >> 4;
+    const int cslices = C >> 6;
+    const int cs = blockIdx.x % cslices, b = blockIdx.x / cslices;
+    const int ty = tile / p.TX, tx = tile - ty * p.TX;
+    const int my = a.pl.n[2] + a.pl.n[3] > 0, mx = a.pl.n[1] + a.pl.n[3] > 0;
+    const bool rF2 = my && ty == p.TY - 1, cF2 = mx && tx == p.TX - 1;
+    const int nfr = rF2 ? 4 : 6, nfc = cF2 ? 4 : 6;
+    // row of this tile in plane 0 of its class, and the class's plane stride (constant indices: a lane-dependent index into the argument
+    // struct would go through scratch memory)
+    const int n_c = rF2 ? (cF2 ? a.pl.n[3] : a.pl.n[2]) : (cF2 ? a.pl.n[1] : a.pl.n[0]);
+    const int rows_c = rF2 ? (cF2 ? a.pl.rows[3] : a.pl.rows[2]) : (cF2 ? a.pl.rows[1] : a.pl.rows[0]);
+    const int base_c = rF2 ? (cF2 ? a.pl.base[3] : a.pl.base[2]) : (cF2 ? a.pl.base[1] : a.pl.base[0]);
+    const int lidx = rF2 ? (cF2 ? 0 : tx) : (cF2 ? ty : ty * (p.TX - mx) + tx);
+    const int c4 = cs * 16 + c4l;
+    const unsigned off0 = (unsigned)(((base_c + b * n_c + lidx) * C + c4 * 4) * 4);       // byte offset of frequency (0, 0)
+    const unsigned pstride = (unsigned)rows_c * (unsigned)C * 4u;                            // bytes between frequency planes
+    constexpr unsigned OOB = 0x80000000u;
+    if (p.M) {
+        // ---- phase 1: Y = A^T M A, epilogue, LDS image
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.M), 0, a.plane_bytes, 0x00020000);
+        v4f t[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            v4f m[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool ok = i < nfr && j < nfc;
+                m[i] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rm, ok ? off0 + (unsigned)(i * nfc + j) * pstride : OOB, 0, 0));
+            }
+            v4f y4[4];
+            wino_at(m, y4);
+            const v4f y20 = m[0] + m[1] + m[2], y21 = m[1] - m[2] - m[3];
+            t[0][j] = rF2 ? y20 : y4[0];
+            t[1][j] = rF2 ? y21 : y4[1];
+            t[2][j] = y4[2];                                  // (rows 2, 3 of an F(2) tile lie outside the map: never stored)
+            t[3][j] = y4[3];
+        }
+        const v4f b4 = p.bias ? *reinterpret_cast<const v4f*>(p.bias + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+        v4f rs[4][4];                                        // residual reads before the first store (see wino_output_kernel)
+        if (p.res) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int oy = 4 * ty + r, ox = 4 * tx + x;
+                    rs[r][x] = *reinterpret_cast<const v4f*>(p.res + (((size_t)b * p.H + min(oy, p.H - 1)) * p.W + min(ox, p.W - 1)) * C + c4 * 4);   // (clamped: unconditional)
+                }
+        }
+        v4f sl = {0.f, 0.f, 0.f, 0.f}, s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+        if (p.act == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(p.slope + c4 * 4);
+        if (p.s2) { s2 = *reinterpret_cast<const v4f*>(p.s2 + c4 * 4); t2 = *reinterpret_cast<const v4f*>(p.t2 + c4 * 4); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oy = 4 * ty + r;
+            if (oy >= p.H) continue;
+            v4f y[4];
+            wino_at(t[r], y);
+            if (cF2) { y[0] = t[r][0] + t[r][1] + t[r][2]; y[1] = t[r][1] - t[r][2] - t[r][3]; }
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int ox = 4 * tx + x;
+                if (ox >= p.W) continue;
+                v4f v = y[x] + b4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float u = v[e];
+                    if (p.act == (int)Act::RELU) u = u > 0.f ? u : 0.f;
+                    else if (p.act == (int)Act::PRELU) u = u >= 0.f ? u : u * sl[e];
+                    else if (p.act == (int)Act::SIGMOID) u = 1.0f / (1.0f + expf(-u));
+                    v[e] = u;
+                }
+                const size_t o = (((size_t)b * p.H + oy) * p.W + ox) * C + c4 * 4;
+                if (p.res) v += rs[r][x];
+                if (p.out1) *reinterpret_cast<v4f*>(p.out1 + o) = v;
+                const v4f vb = v * s2 + t2;
+                if (p.out2) *reinterpret_cast<v4f*>(p.out2 + o) = vb;
+                act[(oy * p.W + ox) * 16 + c4l] = a.feed_aff ? vb : v;
+            }
+        }
+    } else {
+        // ---- the image comes from memory (first convolution of a chain): whole 256-byte pixel rows per 16 lanes
+        v4f as4 = {1.f, 1.f, 1.f, 1.f}, at4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.in_s) { as4 = *reinterpret_cast<const v4f*>(a.in_s + c4 * 4); at4 = *reinterpret_cast<const v4f*>(a.in_t + c4 * 4); }
+        const float* src = a.in + (size_t)b * HW * C + c4 * 4;
+        for (int px = tile; px < HW; px += 16) act[px * 16 + c4l] = *reinterpret_cast<const v4f*>(src + (size_t)px * C) * as4 + at4;
+    }
+    if (!a.V) return;
+    __syncthreads();
+    // ---- phase 2: V = B^T d B from the LDS image (zeros outside the map)
+    const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(a.V, 0, a.plane_bytes, 0x00020000);
+    const v4f* img = act + c4l;
+    const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
+    v4f tt[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int ix = ix0 + c;
+        v4f d[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int iy = iy0 + r;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            d[r] = ok ? img[(iy * p.W + ix) * 16] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        v4f t4[6], t2s[6];
+        wino_bt(d, t4);
+        wino_bt2s(d, t2s);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tt[i][c] = rF2 ? t2s[i] : t4[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v4f o4[6], o2[6];
+        wino_bt(tt[i], o4);
+        wino_bt2s(tt[i], o2);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const bool ok = i < nfr && j < nfc;
+            const v4f o = cF2 ? o2[j] : o4[j];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, a.pack ? wino_pack_bf16x2(o) : o), rv,
+                                                   ok ? off0 + (unsigned)(i * nfc + j) * pstride : OOB, 0, 0);
+        }
+    }
+}
+
+void launch_wino_mix(const ConvArgs& a, const WinoPlanes& pl, const float* M, float* Vnext, int feed_aff, const float* in_scale,
+                     const float* in_shift, bool pack_next, hipStream_t s) {
+    if (a.B <= 0) return;
+    WinoMixArgs f{};
+    f.o = wino_out_args(a, M);
+    if (!M) { f.o.C = a.Cin; f.o.res = nullptr; f.o.out1 = f.o.out2 = nullptr; }
+    f.pl = pl;
+    f.in = a.in; f.in_s = in_scale; f.in_t = in_shift;
+    f.V = Vnext; f.feed_aff = feed_aff; f.pack = pack_next ? 1 : 0;
+    long rows = 0;
+    for (int c = 0; c < 4; ++c) rows += (long)((c & 2) ? 4 : 6) * pl.nfc[c] * pl.rows[c];
+    f.plane_bytes = (unsigned)(rows * f.o.C * 4);
+    if (f.o.C % 64 || f.o.TY * f.o.TX != 16 || rows * f.o.C * 4 >= (1L << 31)) throw std::runtime_error("winograd: this map cannot take the mixed tiling");
+    const size_t lds = (size_t)a.H * a.W * 16 * sizeof(v4f);
+    KernelTimer& timer = KernelTimer::get();
+    timer.begin(s);
+    hipLaunchKernelGGL(wino_mix_kernel, dim3((unsigned)(a.B * (f.o.C / 64))), dim3(256), lds, s, f);
+    timer.end(s, 8, 0.0, 0.0);
+}
+
 // all three stages of one convolution (used by the single-layer test entry point)
 void launch_conv_winograd(const ConvArgs& a, const float* wt36, float* V, float* M, int cfg, const float* in_scale, const float* in_shift,
                           hipStream_t s) {
+    WinoPlanes pl;
+    if (cfg == 2 && wino_mix_layout(a.B, a.H, a.W, a.Cin, a.Cout, &pl)) {
+        launch_wino_mix(a, pl, nullptr, V, 0, in_scale, in_shift, false, s);
+        launch_wino_gemm(a, wt36, V, M, cfg, false, s, &pl);
+        launch_wino_mix(a, pl, M, nullptr, 0, nullptr, nullptr, false, s);
+        return;
+    }
     launch_wino_input(a, V, in_scale, in_shift, false, s);
     launch_wino_gemm(a, wt36, V, M, cfg, false, s);
     launch_wino_output(a, M, s);

@@ -143,6 +143,11 @@ WINO_CASES = [
     (2, 13, 10, 128, 64),
     (1, 5, 9, 160, 36),
     (1, 4, 4, 128, 32),
+    # B >= 64 on 16-tile maps of side 4 k + 2 / 4 k + 1: the mixed F(4x4) / F(2x2) tiling (four tile classes, planes padded to 128 rows;
+    # 16 x 14: only the column direction is mixed, two of the four classes are empty)
+    (64, 14, 14, 128, 64),
+    (70, 13, 14, 64, 128),
+    (64, 16, 14, 64, 64),
 ]
 
 
