@@ -29,12 +29,19 @@
 //     than the k-th of their union, so ~20 of the 32 insertion passes of a tile still fire half-way through the scan;
 //   * the same with chip-wide thresholds through atomicMax on 64 words: 1.18 ms (contended atomics, and the maximum of per-workgroup
 //     k-ths is still not a chip-wide k-th).
+// Where a call's 0.82 ms go (rocprofv3, 1 M x 512, Q = 64, k = 16): seed scan 89 us (32 workgroups, one tile each: a latency chain plus the
+// first-tile insertions) + seed merge 26 + main scan 658 (67.1 GFLOP = 102 TFLOP/s: at Q = 64 the f32 matrix cores bind, not HBM —
+// 0.43 ms at the nominal peak, ~0.58 at the 115 TFLOP/s plateau) + final merge 50.  Without the seed pass (FACEHIP_GAL_SEED=0) the call
+// takes 0.844 ms: the per-workgroup list warm-up costs more than the 115 us the seed does.  A pruned final merge (threshold = best over
+// the parts of a full part's worst entry, survivors compacted to LDS, one entry per thread in the rounds) ran 35 us SLOWER with
+// part-per-thread loads (64 lines per load instruction) and was not kept.
 // Side results worth keeping: a wave streaming its own 32 rows into registers reaches 6.2 TB/s whatever the lane-to-row mapping
 // (scripts/ubench/row_stream.hip: 32, 16, 8 rows per instruction or fully coalesced, all 6.2-6.5 TB/s), so the scan is not bound by
 // its access pattern; with loads and top-k switched off the MFMA + fragment-read loop alone runs at ~75 % of the f32 peak.
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdlib>
 #include <stdexcept>
 
 #include "kernels.h"
@@ -281,7 +288,9 @@ void launch_gallery_topk(const float* gal, long G, int dim, const float* qpacked
     a.tiles_n = (Q + GAL_BN - 1) / GAL_BN;
     a.ps = part_score; a.pi = part_idx;
     constexpr long GAL_SEED_ROWS = 4096;
-    if (G >= 16 * GAL_SEED_ROWS && seed_score && seed_idx) {
+    static int seed_on = -1;
+    if (seed_on < 0) { const char* e = getenv("FACEHIP_GAL_SEED"); seed_on = e ? atoi(e) : 1; }     // (0: no seed pass — A / B timing)
+    if (seed_on && G >= 16 * GAL_SEED_ROWS && seed_score && seed_idx) {
         a.G = GAL_SEED_ROWS;
         a.row_tiles = (int)(GAL_SEED_ROWS / GAL_BM);
         const int sp = gallery_parts(a.G, Q, &a.tiles_per_part);
