@@ -678,15 +678,17 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
 // compiler's wait for the prefetched registers becomes the exact `vmcnt(stores + later loads)` instead of vmcnt(0): the ISA showed
 // vmcnt(21)..(9) as intended, the layers ran no faster and the 16-channel layers slower.
 // C % 8 == 0 (CQ = C / 4 even), Cout % 4 == 0, Cout <= 32 * TN.
-template <int CQ, int TN, int OCC>
+template <int CQ, int TN, int OCC, int DS>
 __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_total) {
     static_assert(CQ % 2 == 0, "whole 8-channel MFMA steps");
     constexpr int C = CQ * 4, STEPS = C / 8;
     constexpr int PQ = CQ + 1;                                             // halo pixel pitch in float4 (odd)
-    constexpr int NPF = (DP_HALO * CQ + 255) / 256;                        // prefetched float4 per thread
+    // halo of an 8 x 16 output tile under a depthwise stride DS: rows 2 oy - 1 .. 2 oy + 1 -> (8 - 1) DS + 3 rows, same for the columns
+    constexpr int HH = (DP_TH - 1) * DS + 3, HWD = (DP_TW - 1) * DS + 3, HALO = HH * HWD;   // 10 x 18 = 180 (DS = 1), 17 x 33 = 561 (DS = 2)
+    constexpr int NPF = (HALO * CQ + 255) / 256;                           // prefetched float4 per thread
     extern __shared__ v4f smem[];
-    v4f* const halo = smem;                                                // [180][PQ]
-    v4f* const dwl = halo + DP_HALO * PQ;                                  // [10][CQ]: 9 taps + bias
+    v4f* const halo = smem;                                                // [HALO][PQ]
+    v4f* const dwl = halo + HALO * PQ;                                  // [10][CQ]: 9 taps + bias
     v4f* const Wl = dwl + 10 * CQ;                                         // [STEPS][2][Cout]: A fragments (n = row, 4 k of half h)
     float* const pwb = reinterpret_cast<float*>(Wl + STEPS * 2 * p.Cout);  // [32 * TN] pointwise bias (zero behind Cout)
 
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 
     // this lane's pixel and fragment addresses (float4 units)
     const int pix = wid * 32 + r, py = pix / DP_TW, px = pix - py * DP_TW;
-    const v4f* const hbase = halo + (py * DP_HW + px) * PQ + h;            // + (ky * 18 + kx) * PQ + 2 j
+    const v4f* const hbase = halo + (py * DS * HWD + px * DS) * PQ + h;    // + (ky * HWD + kx) * PQ + 2 j
     const v4f* const dbase = dwl + h;                                      // + tap * CQ + 2 j
     int wrow[TN];
 #pragma unroll
@@ -728,26 +730,26 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
     int voff[NPF];
 #pragma unroll
     for (int k = 0; k < NPF; ++k) {
-        const int i = min(tid + 256 * k, DP_HALO * CQ - 1);
+        const int i = min(tid + 256 * k, HALO * CQ - 1);
         const int hp = i / CQ, q = i - hp * CQ;
-        const int hy = hp / DP_HW, hx = hp - hy * DP_HW;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
         voff[k] = ((hy * p.W + hx) * C + 4 * q) * 4;
     }
     const int img_bytes = p.H * p.W * C * 4;
     auto prefetch = [&](int t) __attribute__((always_inline)) {
         const int n = t / per_img, rem = t - n * per_img;
         const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
-        const int y0 = tyi * DP_TH - 1, x0 = txi * DP_TW - 1;
+        const int y0 = tyi * DP_TH * DS - 1, x0 = txi * DP_TW * DS - 1;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + (size_t)n * p.H * p.W * C), 0, img_bytes, 0x00020000);
         const int tile_off = (y0 * p.W + x0) * C * 4;                       // (negative on the first tile row / column: wraps out of range)
         int vo[NPF];
 #pragma unroll
         for (int k = 0; k < NPF; ++k) vo[k] = tile_off + voff[k];
-        if (x0 < 0 || x0 + DP_HW > p.W) {                                   // wave-uniform: only the first / last tile column
+        if (x0 < 0 || x0 + HWD > p.W) {                                   // wave-uniform: only the first / last tile column
 #pragma unroll
             for (int k = 0; k < NPF; ++k) {
-                const int i = min(tid + 256 * k, DP_HALO * CQ - 1);
-                const int hx = (i / CQ) % DP_HW;
+                const int i = min(tid + 256 * k, HALO * CQ - 1);
+                const int hx = (i / CQ) % HWD;
                 vo[k] = (unsigned)(x0 + hx) < (unsigned)p.W ? vo[k] : (int)0x80000000;
             }
         }
@@ -776,7 +778,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int i = tid + 256 * k;
-            if (i < DP_HALO * CQ) halo[i + i / CQ] = pf[k];              // pixel pitch PQ = CQ + 1
+            if (i < HALO * CQ) halo[i + i / CQ] = pf[k];              // pixel pitch PQ = CQ + 1
         }
         DWPW_STAMP(1)
         if (t + wgs < run1) prefetch(t + wgs);
@@ -806,7 +808,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
             const int jj = G / NT, tt = G % NT;
             if (jj >= STEPS) return;
             dv[G % RING] = dbase[(tt == 0 ? 9 : tt - 1) * CQ + 2 * jj];
-            if (tt > 0) hv[G % RING] = hbase[(((tt - 1) / 3) * DP_HW + (tt - 1) % 3) * PQ + 2 * jj];
+            if (tt > 0) hv[G % RING] = hbase[(((tt - 1) / 3) * HWD + (tt - 1) % 3) * PQ + 2 * jj];
         };
         v4f an;
         auto consume = [&](int G) __attribute__((always_inline)) {
@@ -837,7 +839,11 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
             }
         }
         DWPW_STAMP(4)
-        // ---- epilogue: lane = pixel, accumulator quads = 4 consecutive channels
+        // ---- epilogue: lane = pixel, accumulator quads = 4 consecutive channels.
+        // (Stride-2 form, 320x320x16 -> 160x160x40: the phase stamps show stores 6.3 k + next prefetch's issue 4.1 k of 16.4 k cycles per
+        // tile — queueing behind the memory pipeline.  Parking the wave's pixels in the halo rows it owns exclusively (4 wid + 1 .. + 3) and
+        // writing them back as whole lines changed nothing (296 vs 301 us, stores still 5.9 k): it is the 4.6 TB/s of mixed read / write
+        // traffic itself, not the 16-byte pieces, that the block waits for.)
         const int oy = ty0 + py, ox = tx0 + px;
         if (oy < p.Ho && ox < p.Wo) {
             float* __restrict__ orow = p.out1 + (((size_t)n * p.Ho + oy) * p.Wo + ox) * Cout;
@@ -871,35 +877,46 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 // different 128-byte lines (16 bytes each, stride 2 pixels): the loads are bound by tag look-ups, not by bytes.  The strip form of
 // dwpw_kernel (lane = 16-byte channel column, 4 lanes per 64-byte pixel) keeps them coalesced and stays.
 
-static size_t dwpw_reg_lds(int CQ, int Cout, int TN) {
-    return ((size_t)DP_HALO * (CQ + 1) + 10 * CQ + (size_t)(CQ / 2) * 2 * Cout) * 16 + (size_t)32 * TN * 4;
+static size_t dwpw_reg_lds(int CQ, int Cout, int TN, int DS) {
+    const int halo = ((DP_TH - 1) * DS + 3) * ((DP_TW - 1) * DS + 3);
+    return ((size_t)halo * (CQ + 1) + 10 * CQ + (size_t)(CQ / 2) * 2 * Cout) * 16 + (size_t)32 * TN * 4;
 }
 static bool dwpw_reg_enabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("FACEHIP_DWPW_REG"); v = e ? atoi(e) : 1; }
     return v != 0;
 }
-template <int CQ, int TN, int OCC>
+template <int CQ, int TN, int OCC, int DS = 1>
 static void launch_dwpw_reg_cfg(const ConvArgs& a, hipStream_t s) {
     const int tiles_x = (a.Wo + DP_TW - 1) / DP_TW, tiles_y = (a.Ho + DP_TH - 1) / DP_TH;
     const int tiles_total = a.B * tiles_y * tiles_x;
     const int cus = a.cus > 0 ? a.cus : conv_num_cus();
-    const size_t lds = dwpw_reg_lds(CQ, a.Cout, TN);
+    const size_t lds = dwpw_reg_lds(CQ, a.Cout, TN, DS);
     static bool attr_set = false;                                          // (per instantiation) dynamic LDS beyond the 64 KB default needs the opt-in
     if (!attr_set) {
-        FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpw_reg_kernel<CQ, TN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpw_reg_kernel<CQ, TN, OCC, DS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     int grid = std::min((tiles_total + 7) / 8 * 8, cus * OCC);
     grid = std::max(8, grid / 8 * 8);
-    hipLaunchKernelGGL((dwpw_reg_kernel<CQ, TN, OCC>), dim3((unsigned)grid), dim3(256), lds, s, a, tiles_x, tiles_y, tiles_total);
+    hipLaunchKernelGGL((dwpw_reg_kernel<CQ, TN, OCC, DS>), dim3((unsigned)grid), dim3(256), lds, s, a, tiles_x, tiles_y, tiles_total);
 }
 // true = launched.  Instantiated for SCRFD-500M's stride-1 blocks (C = 16 / 40 / 64 / 72) with any Cout <= 96.
 static bool launch_dwpw_reg(const ConvArgs& a, hipStream_t s) {
-    if (!dwpw_reg_enabled() || a.dw_stride != 1 || a.u8_src || a.Cout % 4 || a.Cout > 96 || a.H != a.Ho || a.W != a.Wo) return false;
+    if (!dwpw_reg_enabled() || a.u8_src || a.Cout % 4 || a.Cout > 96) return false;
     if (a.act != (int)Act::NONE && a.act != (int)Act::RELU) return false;
     if ((long)a.H * a.W * a.Cin * 4 >= (1L << 31)) return false;            // one image must fit a 32-bit buffer range
     const int tn = (a.Cout + 31) / 32;
+    if (a.dw_stride == 2) {
+        // the stride-2 block of 16 channels (SCRFD: 320x320x16 -> 160x160x40): a 17 x 33 halo of all channels is 45 KB, three workgroups per
+        // CU; with 40 channels it would be 99 KB (one workgroup per CU) — those blocks stay with dwpw_kernel
+        static int s2 = -1;
+        if (s2 < 0) { const char* e = getenv("FACEHIP_DWPW_REG_S2"); s2 = e ? atoi(e) : 1; }
+        if (!s2 || a.Cin != 16 || tn > 2 || a.Ho != (a.H - 1) / 2 + 1 || a.Wo != (a.W - 1) / 2 + 1) return false;
+        if (tn == 1) launch_dwpw_reg_cfg<4, 1, 3, 2>(a, s); else launch_dwpw_reg_cfg<4, 2, 3, 2>(a, s);
+        return true;
+    }
+    if (a.dw_stride != 1 || a.H != a.Ho || a.W != a.Wo) return false;
     switch (a.Cin) {
         case 16:
             if (tn == 1) launch_dwpw_reg_cfg<4, 1, 4>(a, s); else if (tn == 2) launch_dwpw_reg_cfg<4, 2, 4>(a, s); else launch_dwpw_reg_cfg<4, 3, 3>(a, s);

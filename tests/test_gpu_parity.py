@@ -97,7 +97,9 @@ DWPW_CASES = [
     (40, 40, 16, 64, 1),
     (45, 41, 72, 72, 1),
     (37, 90, 40, 24, 1),
-    (160, 160, 16, 40, 2),
+    (160, 160, 16, 40, 2),             # 16 channels, stride 2: the register-fed form with a 17 x 33 halo (dwpw_reg_kernel<.., 2>)
+    (163, 175, 16, 40, 2),             # ... odd map: ragged last tile row / column, right / bottom padding inside the halo
+    (170, 162, 16, 24, 2),
     (163, 175, 40, 72, 2),
     (161, 166, 20, 100, 2),
 ]
