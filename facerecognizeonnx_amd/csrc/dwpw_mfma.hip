@@ -418,8 +418,9 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
         g_rq[i] = rr;
         g_cb[i] = g_hx[i] * S * 3 + (g < 3 ? 0 : 8);
     }
-    // a halo pixel's window lies inside the frame (and the pixel inside the map) iff  AY0 <= ay <= AY1  and  AX0 <= ax <= AX1
-    const int AY0 = 1, AY1 = min(p.H - 1, (p.u8_srcH - 2) / S), AX0 = (2 + S - 1) / S, AX1 = min(p.W - 1, (p.u8_srcW - 3) / S);
+    // a halo pixel lies inside the map and its 3x3 window inside the net input iff  AY0 <= ay <= AY1  and  AX0 <= ax <= AX1 (tiles whose
+    // whole halo does take the plain path; the others patch the conv padding in, see the stem below)
+    const int AY0 = 1, AY1 = min(p.H - 1, (p.u8_inH - 2) / S), AX0 = 1, AX1 = min(p.W - 1, (p.u8_inW - 2) / S);
 
     // ---- tiles of this workgroup: XCD x owns a contiguous run, its workgroups walk it side by side (t, t + wgs, ...); the tile
     // coordinates move by the same three steps every time: no division in the loop
@@ -446,10 +447,12 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
             const int r = pr + (256 / FR_PITCH) * k;
             const unsigned shr = (STEP4 ? base_lo : base_lo + (unsigned)(r * step)) & 3u;
             const int rel = sx3 - (int)shr + pd4;                            // byte position in the frame row
-            // dwords that are not entirely inside the frame's row read as 0: only border pixels would look at them, and those take
-            // the per-byte path
-            const bool ok = r < nrows && (unsigned)(sy0 + r) < (unsigned)p.u8_srcH && rel >= 0 && rel + 4 <= row_bytes;
-            pf[k] = ok ? *(const dwpw_gmem_u32*)(frame + (unsigned)((sy0 + r) * step + rel)) : 0u;
+            // rows / dwords outside the pasted image read as 0 (the letterbox canvas).  A dword that straddles an end of the row is read
+            // from the clamped position — the last / first four bytes of the row, an unaligned but in-bounds access — and shifted into
+            // place when it is staged (stage_fix below), so every byte of the image is exact in the staged window
+            const bool ok = r < nrows && (unsigned)(sy0 + r) < (unsigned)p.u8_srcH && rel > -4 && rel < row_bytes;
+            const int relc = min(max(rel, 0), row_bytes - 4);
+            pf[k] = ok ? *(const dwpw_gmem_u32*)(frame + (unsigned)((sy0 + r) * step + relc)) : 0u;
         }
     };
 
@@ -477,23 +480,35 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
         const int sy0 = (cty0 - 1) * S - 1, sx0 = (ctx0 - 1) * S - 1;
         const unsigned base_lo = (unsigned)(unsigned long long)frame + (unsigned)(sy0 * step + sx0 * 3);
         // 1. window: registers -> LDS (waits for the loads issued a whole tile ago), then the next tile's loads
+        // (the whole halo in the map and every window inside the net input: AY1 <= H - 1, AX1 <= W - 1)
+        const bool tile_inside = cty0 - 1 >= AY0 && cty0 + DP_TH <= AY1 && ctx0 - 1 >= AX0 && ctx0 + DP_TW <= AX1;
 #pragma unroll
-        for (int k = 0; k < FR_SLOTS; ++k)
-            if (tid + 256 * k < FR_ROWS * FR_PITCH) stage[buf][tid + 256 * k] = pf[k];
+        for (int k = 0; k < FR_SLOTS; ++k) {
+            unsigned v = pf[k];
+            if (sx0 * 3 < 4 || sx0 * 3 + 4 * FR_PITCH > row_bytes) {        // (wave-uniform: the window reaches an end of the image's rows — the
+                                                                            //  frame's border or the letterbox edge) clamped dwords: bytes into place
+                const int r = pr + (256 / FR_PITCH) * k;
+                const unsigned shr = (STEP4 ? base_lo : base_lo + (unsigned)(r * step)) & 3u;
+                const int rel = sx0 * 3 - (int)shr + pd4;
+                const int dl = min(max(rel, 0), row_bytes - 4) - rel;       // > 0: straddles the row's start, < 0: its end
+                const unsigned sh = 8u * (unsigned)min(abs(dl), 3);
+                v = dl > 0 ? v << sh : dl < 0 ? v >> sh : v;
+            }
+            if (tid + 256 * k < FR_ROWS * FR_PITCH) stage[buf][tid + 256 * k] = v;
+        }
         FRONT_STAMP(0)
         advance();
         if (t + wgs < run1) prefetch();
         FRONT_STAMP(1)
         front_barrier();
         FRONT_STAMP(2)
-        // 2. stem.  Pass FAST: every pixel whose 3x9-byte window lies inside the frame, from the staged image — no global access, so no
-        // wait on the prefetch.  Pass BORDER (only tiles that touch the frame's border, a wave-uniform test): the remaining pixels, byte by
-        // byte from global memory (outside the net input = conv zero padding: 127.5 cancels against the folded bias; inside it but outside
-        // the pasted image = letterbox canvas, u8 0).  Kept apart because a global load anywhere in the common loop makes the compiler
-        // drain vmcnt at its join — i.e. wait for the NEXT tile's window in every group.
+        // 2. stem, every pixel from the staged image — no global access in this loop, so nothing here waits on the prefetch (a global load
+        // anywhere in it would make the compiler drain vmcnt at its join: the NEXT tile's window, in every group).  Tiles that touch the
+        // border of the map (wave-uniform test) patch the convolution's zero padding in: a byte OUTSIDE the net input counts as 127.5 —
+        // it cancels against the folded (v - 127.5) / 128 — while the letterbox canvas (inside the net input, outside the pasted image)
+        // is the u8 0 the staged window already holds.  Round 2 / early round 3 sent those pixels through a second, per-byte pass over
+        // global memory: border tiles (14.5 % of a 640x640 frame's) cost twice an inner tile and the slowest wave ran 20 % above the mean.
         const unsigned* st = stage[buf];
-        // (the whole halo in the map and every window in the frame: AY1 <= H - 1, AX1 <= W - 1)
-        const bool tile_inside = cty0 - 1 >= AY0 && cty0 + DP_TH <= AY1 && ctx0 - 1 >= AX0 && ctx0 + DP_TW <= AX1;
         auto stem_finish = [&](const float (&f)[8], bool inmap, bool store, int hp) __attribute__((always_inline)) {
             v4u bq;                                                         // fp32 -> bf16 by truncation: exact for 0..255 and 127.5
 #pragma unroll
@@ -515,16 +530,11 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
 #pragma unroll
         for (int i = 0; i < NG; ++i) {                                      // (wave-uniform trip count: the MFMAs run with all lanes)
             const int hp = g_hp[i];
-            bool inmap = hp >= 0, fast = inmap;
-            if (!tile_inside) {
-                const int ay = cty0 + g_hy[i] - 1, ax = ctx0 + g_hx[i] - 1;
-                inmap = inmap && (unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W;
-                fast = inmap && ay >= AY0 && ay <= AY1 && ax >= AX0 && ax <= AX1;
-            }
+            bool inmap = hp >= 0;
             float f[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = 0.f;
-            if (fast) {
+            if (hp >= 0) {
                 if (g < 3) {                                                // 8 bytes at an unaligned position: 3 aligned dwords
                     const unsigned pos = ((STEP4 ? base_lo : base_lo + (unsigned)(g_rq[i] * step)) & 3u) + (unsigned)g_cb[i];
                     const unsigned* q = st + g_rq[i] * FR_PITCH + (pos >> 2);
@@ -541,37 +551,21 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
                     }
                 }
             }
-            stem_finish(f, inmap, hp >= 0, hp);
-        }
-        if (!tile_inside) {
-            // BORDER pass: the pixels the FAST pass could not do (it stored zeros or garbage-free zeros for them), same lanes, same wave
-#pragma unroll 1
-            for (int i = 0; i < NG; ++i) {
-                if ((wid + 4 * i) * 16 >= DP_HALO) break;
-                const int hp = g_hp[i];
+            if (!tile_inside) {
                 const int ay = cty0 + g_hy[i] - 1, ax = ctx0 + g_hx[i] - 1;
-                const bool inmap = hp >= 0 && (unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W;
-                const bool slow = inmap && !(ay >= AY0 && ay <= AY1 && ax >= AX0 && ax <= AX1);
-                const int iy0 = ay * S - 1, ix0 = ax * S - 1;
-                float f[8];
+                inmap = inmap && (unsigned)ay < (unsigned)p.H && (unsigned)ax < (unsigned)p.W;
+                const int iyb = ay * S - 1, ixb = ax * S - 1;               // window origin in the net input
+                const bool c0 = (unsigned)ixb >= (unsigned)p.u8_inW, c1 = (unsigned)(ixb + 1) >= (unsigned)p.u8_inW, c2 = (unsigned)(ixb + 2) >= (unsigned)p.u8_inW;
+                if (g < 3) {                                                // bytes 0..7 of window row g: columns 0 0 0 1 1 1 2 2
+                    const bool ro = (unsigned)(iyb + g) >= (unsigned)p.u8_inH;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) f[j] = 0.f;
-                if (slow) {
+                    for (int j = 0; j < 8; ++j) f[j] = (ro || (j < 3 ? c0 : j < 6 ? c1 : c2)) ? 127.5f : f[j];
+                } else {                                                    // byte 8 (column 2) of rows 0..2
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int r = g < 3 ? g : j, rb = g < 3 ? j : 8;     // window row, byte within the row (pixel rb / 3, channel rb % 3)
-                        if (g == 3 && j >= 3) continue;
-                        const int iy = iy0 + r, ix = ix0 + rb / 3;
-                        float b = 127.5f;
-                        if ((unsigned)iy < (unsigned)p.u8_inH && (unsigned)ix < (unsigned)p.u8_inW) {
-                            b = 0.f;
-                            if (iy < p.u8_srcH && ix < p.u8_srcW) b = (float)frame[(size_t)iy * step + (size_t)ix * 3 + rb % 3];
-                        }
-                        f[j] = b;
-                    }
+                    for (int r = 0; r < 3; ++r) f[r] = ((unsigned)(iyb + r) >= (unsigned)p.u8_inH || c2) ? 127.5f : f[r];
                 }
-                stem_finish(f, inmap, slow, hp);
             }
+            stem_finish(f, inmap, hp >= 0, hp);
         }
         FRONT_STAMP(3)
         front_barrier();
