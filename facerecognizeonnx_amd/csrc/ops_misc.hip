@@ -60,16 +60,20 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 #pragma unroll
         for (int o = 0; o < STRIP; ++o) acc[o] = b4;
         const int iy0 = oy0 * STRIDE - 1, ix0 = ox * STRIDE - 1;
+        // UNCONDITIONAL loads from clamped coordinates, zeroed by a multiply afterwards: a load under a branch is waited for at the
+        // branch's join — three latency chains of ROWS loads per thread instead of 3 x ROWS loads in flight (same rule as wino_input_kernel)
+        const float* imgp = in + (size_t)n * H * W * C + c4 * 4;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = ix0 + kx;
-            if ((unsigned)ix >= (unsigned)W) continue;
-            const float* colp = in + ((size_t)n * H * W + ix) * C + c4 * 4;
+            const bool okx = (unsigned)ix < (unsigned)W;
+            const int ixc = min(max(ix, 0), W - 1);
             v4f x[ROWS];
 #pragma unroll
             for (int ridx = 0; ridx < ROWS; ++ridx) {
                 const int iy = iy0 + ridx;
-                x[ridx] = (unsigned)iy < (unsigned)H ? *reinterpret_cast<const v4f*>(colp + (size_t)iy * W * C) : v4f{0.f, 0.f, 0.f, 0.f};
+                const float okf = okx && (unsigned)iy < (unsigned)H ? 1.f : 0.f;
+                x[ridx] = *reinterpret_cast<const v4f*>(imgp + ((size_t)min(max(iy, 0), H - 1) * W + ixc) * C) * okf;
             }
 #pragma unroll
             for (int o = 0; o < STRIP; ++o)
@@ -115,16 +119,18 @@ __global__ __launch_bounds__(256) void dwconv3x3_hstrip_kernel(const float* __re
 #pragma unroll
         for (int o = 0; o < STRIP; ++o) acc[o] = b4;
         const int iy0 = oy * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+        const float* imgp = in + (size_t)n * H * W * C + c4 * 4;           // (unconditional clamped loads: see dwconv3x3_kernel)
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = iy0 + ky;
-            if ((unsigned)iy >= (unsigned)H) continue;
-            const float* rowp = in + ((size_t)n * H + iy) * W * C + c4 * 4;
+            const bool oky = (unsigned)iy < (unsigned)H;
+            const float* rowp = imgp + (size_t)min(max(iy, 0), H - 1) * W * C;
             v4f x[COLS];
 #pragma unroll
             for (int cidx = 0; cidx < COLS; ++cidx) {
                 const int ix = ix0 + cidx;
-                x[cidx] = (unsigned)ix < (unsigned)W ? *reinterpret_cast<const v4f*>(rowp + (size_t)ix * C) : v4f{0.f, 0.f, 0.f, 0.f};
+                const float okf = oky && (unsigned)ix < (unsigned)W ? 1.f : 0.f;
+                x[cidx] = *reinterpret_cast<const v4f*>(rowp + (size_t)min(max(ix, 0), W - 1) * C) * okf;
             }
 #pragma unroll
             for (int o = 0; o < STRIP; ++o)
