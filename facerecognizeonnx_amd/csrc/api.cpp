@@ -632,7 +632,7 @@ int fh_topk_merge_dev(const float* ps, const int* pi, int nparts, int nq, int k,
 // ---------------------------------------------------------------------------------- timing / tuning
 int fh_timing_enable(int on) { fh::KernelTimer::get().enabled = on != 0; return FH_OK; }
 int fh_timing_collect(double* ms, double* flops, double* bytes, long long* launches, int n) {
-    if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need 11-entry arrays");
+    if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need 12-entry arrays");
     return guarded([&] { fh::KernelTimer::get().collect(ms, flops, bytes, launches); return fh::KernelTimer::kTags; });
 }
 int fh_timing_collect_ops(double* ms, double* flops, int* tag, int cap) {

@@ -788,6 +788,132 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_tall_kernel(const Conv
     conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane, -1, -1, ep);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// conv_pw_kernel (round 3) — 1x1 stride-1 convolutions as the plain GEMM they are: out [M][N] = in [M][K] * W^T.
+// conv_igemm_kernel spends ~650 vector + ~490 scalar instructions per wave on tap / padding / index bookkeeping around the MFMAs of a
+// short-K tile (that is why the Winograd GEMMs got wino_gemm_kernel); SCRFD's 1x1 convolutions (K = 72 / 152 / 288, 0.8 ms of the
+// detector at B = 128) and MobileFaceNet's ran at 65-88 TFLOP/s in it.  Here: wino_gemm_kernel's loop — rows are contiguous, a lane's
+// source address only advances by 32 floats per chunk — with a zero-line source for the float4 columns behind K in the last chunk
+// (K % 4 == 0, any remainder), 128 x BN tiles with BN = 96 (N = 288: three exact column tiles) / 64 / 32, and the shared
+// conv_epilogue (bias, ReLU / PReLU, residual incl. the FPN's 2x upsampled one, second output) with its vectors parked in LDS.
+// M % 128 == 0 (whole tiles) and at least one tile per resident slot, else launch_conv keeps the generic kernel and its stream-K.
+template <int BN, int OCC>
+__global__ __launch_bounds__(256, OCC) void conv_pw_kernel(const ConvArgs p, const int tiles_n, const int chunks) {
+    constexpr int BM = 128, TN = BN / 32, AL = BM / 32, BL = BN / 32;
+    __shared__ v4f lds[2][(BM + BN) * 8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh2 = lane >> 5, fsw = (fr >> 1) & 7;
+    const int nb = gridDim.x, q = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+    const int tile = x * q + min(x, r8) + (blockIdx.x >> 3);                // XCD-contiguous tile order
+    const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int K = p.Cin;
+
+    const int lrow = tid >> 3;
+    const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);                          // source k-column of this lane (swizzle on the source side)
+    const float* a_src = p.in + (size_t)(m0 + lrow) * K + lqs * 4;
+    const float* b_src = p.wt + (size_t)(n0 + lrow) * p.Kpad + lqs * 4;
+    const size_t a32 = (size_t)32 * K, b32 = (size_t)32 * p.Kpad;
+    const float* const zsrc = p.zeros + lqs * 4;
+    int kleft = K - lqs * 4;                                                // > 0: this lane's float4 of the current chunk lies inside a row
+    v4f* const dstA = &lds[0][wid * 64];
+    v4f* const dstB = &lds[0][BM * 8 + wid * 64];
+    auto load_chunk = [&](int buf) {
+        v4f* const dA = dstA + buf * ((BM + BN) * 8);
+        v4f* const dB = dstB + buf * ((BM + BN) * 8);
+        const bool in_k = kleft > 0;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) lds_dma16(in_k ? a_src + i * a32 : zsrc, dA + i * 32 * 8);
+#pragma unroll
+        for (int i = 0; i < BL; ++i) lds_dma16(b_src + i * b32, dB + i * 32 * 8);
+        a_src += 32; b_src += 32; kleft -= 32;
+    };
+    v16f acc[1][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][j][e] = 0.f;
+
+    // the epilogue's per-channel vectors (see conv_epilogue: ep), parked in LDS after the K loop
+    constexpr int EPN = (12 * BN + 255) / 256;
+    float epv[EPN];
+#pragma unroll
+    for (int k = 0; k < EPN; ++k) {
+        const int e = tid + k * 256, a = e / BN, c = e - a * BN, co = n0 + c;
+        float v = 0.f;
+        if (a < 12 && co < p.Cout) {
+            if (a < 9) { if (p.bias && (a == 0 || p.bias_cls)) v = p.bias[a * p.Cout + co]; }
+            else if (a == 9) { if (p.act == (int)Act::PRELU) v = p.slope[co]; }
+            else if (p.out2) v = a == 10 ? p.s2[co] : p.t2[co];
+        }
+        epv[k] = v;
+    }
+
+    load_chunk(0);
+    __syncthreads();
+    for (int kc = 0; kc < chunks; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < chunks) load_chunk(buf ^ 1);
+        const v4f* X = lds[buf] + (wid * 32 + fr) * 8;
+        const v4f* Wt = lds[buf] + BM * 8 + fr * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = (2 * s + fh2) ^ fsw;
+            const v4f xv = X[col];
+            v4f w[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) w[j] = Wt[j * 32 * 8 + col];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j][e], xv[e], acc[0][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* const ep = reinterpret_cast<float*>(&lds[0][0]);
+#pragma unroll
+    for (int k = 0; k < EPN; ++k) {
+        const int e = tid + k * 256;
+        if (e < 12 * BN) ep[e] = epv[k];
+    }
+    __syncthreads();
+    conv_epilogue<BM, BN, 4, 1>(p, acc, m0, n0, wid, 0, lane, -1, -1, ep);
+}
+
+template <int BN, int OCC>
+static void launch_pw_cfg(const ConvArgs& a, long M, hipStream_t s) {
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    KernelTimer& timer = KernelTimer::get();
+    timer.begin(s);
+    hipLaunchKernelGGL((conv_pw_kernel<BN, OCC>), dim3((unsigned)((M / 128) * tiles_n)), dim3(256), 0, s, a, tiles_n, a.Kpad / 32);
+    timer.end(s, 11, a.t_flops, a.t_bytes);
+}
+
+// true = launched
+static bool launch_pw(ConvArgs a, hipStream_t s) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("FACEHIP_CONV_PW"); on = e ? atoi(e) : 1; }       // (0 = conv_igemm_kernel everywhere: A / B timing)
+    const long M = (long)a.B * a.Ho * a.Wo;
+    if (!on || a.no_pw || a.ks != 1 || a.stride != 1 || a.pad != 0 || a.wt_group_rows > 0 || a.sc_in || a.n_outs > 0 || (a.Cin & 3) || (a.Cout & 3) ||
+        (M & 127) || a.H != a.Ho || a.W != a.Wo || a.Kpad % 32 || a.Kpad < a.Cin)
+        return false;
+    a.zeros = conv_zero_line();
+    const int cus = a.cus > 0 ? a.cus : conv_num_cus();
+    auto cols = [&](int bn) { return (a.Cout + bn - 1) / bn * bn; };
+    // widest tile whose padded columns cost <= 7 %; the 32-wide one otherwise (the generic kernel pads the same way)
+    int bn = 32;
+    if (cols(64) * 100 <= a.Cout * 107) bn = 64;
+    if (cols(96) * 100 <= a.Cout * 107 && cols(96) <= cols(64)) bn = 96;
+    const long tiles = (M / 128) * (cols(bn) / bn);
+    const int occ = bn == 96 ? 2 : bn == 64 ? 3 : 4;
+    if (tiles < (long)cus * occ) return false;                              // too few tiles to fill the chip: the generic kernel cuts K
+    if (bn == 96) launch_pw_cfg<96, 2>(a, M, s);
+    else if (bn == 64) launch_pw_cfg<64, 3>(a, M, s);
+    else launch_pw_cfg<32, 4>(a, M, s);
+    return true;
+}
+
 static int tall_enabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("FACEHIP_CONV_TALL"); v = e ? atoi(e) : 1; }       // (0 = conv_igemm_kernel everywhere: A / B timing)
@@ -999,6 +1125,7 @@ void launch_conv(const ConvArgs& a, int cfg, hipStream_t s) {
     if (a.sc_in && (a.ks != 3 || a.Cin % 32 != 0 || a.sc_C % 32 != 0 || a.Kpad != 9 * a.Cin + a.sc_C || a.wt_group_rows > 0 ||
                     (long)a.B * a.sc_H * a.sc_W * a.sc_C >= (1L << 31)))
         throw std::runtime_error("conv: folded shortcut needs a 3x3 convolution with Cin % 32 == 0, sc_C % 32 == 0 and Kpad = 9*Cin + sc_C");
+    if (launch_pw(a, s)) return;
     if (cfg < 0) cfg = conv_pick_cfg(M, a.Cout);
     switch (cfg) {
         case 0: launch_cfg<128, 128, 2, 2, 2>(a, 2, 0, s); break;

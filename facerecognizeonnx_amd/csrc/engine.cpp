@@ -409,6 +409,7 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 a.slabs = partial_.as<float>();
                 a.sk_enable = sk_enable ? 1 : 0;
                 a.cus = cus;
+                a.no_pw = force_cfg >= 0 ? 1 : 0;
                 a.B = batch; a.H = op.H; a.W = op.W; a.Cin = op.Cin; a.Ho = op.Ho; a.Wo = op.Wo; a.Cout = op.Cout;
                 a.ks = op.ks; a.stride = op.stride; a.pad = op.pad; a.Kpad = d.Kpad;
                 a.act = (int)op.act; a.res_mode = (int)op.res_mode;

@@ -15,7 +15,7 @@ void hip_check(hipError_t e, const char* what);
 // Optional per-launch HIP-event timing of the network kernels (bench.py's roofline leg).
 // Tags: 0..3 = conv_igemm tile configs, 4 = depthwise conv, 5 = other graph ops, 6 = conv stream-K fix-up.
 struct KernelTimer {
-    static constexpr int kTags = 11;     // 0-3 conv tile configs, 4 dw / dwpw, 5 other, 6 fix-up, 7 Winograd GEMM, 8 Winograd transforms, 9 halo conv, 10 conv_tall_kernel
+    static constexpr int kTags = 12;     // 0-3 conv tile configs, 4 dw / dwpw, 5 other, 6 fix-up, 7 Winograd GEMM, 8 Winograd transforms, 9 halo conv, 10 conv_tall_kernel, 11 conv_pw_kernel
     bool enabled = false;
     void begin(hipStream_t s);
     void end(hipStream_t s, int tag, double flops, double bytes);
@@ -75,6 +75,7 @@ struct ConvArgs {
     const float* stem_wf;
     const float* stem_bf;
     const unsigned* stem_wfrag;   // launch_dwpw's fused stem: stem_wf as bf16 MFMA fragments (stem_pack_wfrag)
+    int no_pw;              // 1: keep conv_igemm_kernel even where conv_pw_kernel (the lean 1x1 form) would take the layer (forced-cfg runs)
     int n_outs;             // > 0: merged sibling convs — channels [oc0[g], oc0[g+1]) go to outs[g] with act oact[g]
     float* outs[3];
     int oc0[4];

@@ -178,7 +178,7 @@ FH_API int fh_gallery_label_dev(fh_gallery* g, const float* d_queries, int nq, f
 /* ---- measurement hooks (bench.py): per-launch HIP-event timing of the network kernels.
  * Tags 0..3 = conv_igemm tile configs (128x128, 256x64, 128x32, 64x64), 4 = depthwise / depthwise+pointwise,
  * 5 = other graph ops, 6 = conv stream-K fix-up, 7 = Winograd GEMM (its FLOPs = executed; bytes slot = the layer's
- * direct-form FLOPs), 8 = Winograd transforms, 9 = spatial-tile (LDS halo) 3x3 convolutions, 10 = conv_tall_kernel (whole tile rounds of the 3x3 stride-1 layers).  fh_timing_collect synchronises, fills 11-entry arrays (elapsed ms,
+ * direct-form FLOPs), 8 = Winograd transforms, 9 = spatial-tile (LDS halo) 3x3 convolutions, 10 = conv_tall_kernel (whole tile rounds of the 3x3 stride-1 layers), 11 = conv_pw_kernel (1x1 stride-1 convolutions as plain GEMMs).  fh_timing_collect synchronises, fills 12-entry arrays (elapsed ms,
  * algorithmic FLOP, algorithmic activation bytes, launches) and resets the counters.
  * fh_*_set_conv_cfg forces one tile config for every dense conv of a handle (-1 = automatic)
  * and switches the stream-K remainder wave on/off (tuning / A-B measurements). */

@@ -59,6 +59,12 @@ CONV_CASES = [
     (35, 61, 63, 64, 64, 3, 1, 1),
     # the 128x32 instantiation (SCRFD's merged head convolutions take it at B = 128): 811 tiles, 768 of them in conv_tall_kernel
     (27, 61, 63, 32, 32, 3, 1, 2),
+    # 1x1 stride-1 layers with whole 128-row tiles and at least one tile per resident slot: conv_pw_kernel (the lean GEMM form) —
+    # 128x96 tiles with K = 288 and with a K tail (152 = 4.75 chunks), 128x32 tiles with N = 152 (padded to 160) and K = 72, 128x64 with K = 40
+    (64, 20, 20, 288, 288, 1, 1, -1),
+    (64, 20, 20, 152, 288, 1, 1, -1),
+    (72, 20, 20, 72, 152, 1, 1, -1),
+    (256, 20, 20, 40, 64, 1, 1, -1),
 ]
 
 
