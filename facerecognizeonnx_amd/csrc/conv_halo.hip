@@ -172,18 +172,104 @@ __global__ __launch_bounds__(256, CIN4 == 4 ? 4 : 3) void conv3x3_halo_kernel(co
         }
 }
 
+// ---- Cout <= 16 (SCRFD's FPN smoothing convolutions, 16 -> 16): v_mfma_f32_16x16x4_f32 instead of padding 16 output channels to the
+// 32 rows of the 32x32 instruction (half of the kernel's matrix-core time multiplied zeros: 80x80 at B = 128 needs 55 us of 32x32x2 issue
+// for 77 us of kernel).  Same halo image, same one barrier.  A wave owns two 16-pixel row segments; lane (j = lane & 15, q = lane >> 4)
+// reads ONE float4 per tap — channels 4q .. 4q+3 of pixel j under that tap — and feeds element s of it to the s-th of four MFMAs: the K
+// index k of step s stands for channel 4k + s, and the weight lane (cout i, k = q) holds the matching float4 w[i][tap][4q .. 4q+3], the
+// filter's natural layout.  D comes back as pixel j, output channels 4q .. 4q+3: one float4 store per lane and segment.
+static inline bool halo16_shape(int Cin, int Cout, int n_outs) { return Cin == 16 && Cout <= 16 && (Cout & 3) == 0 && n_outs == 0; }
+
+__global__ __launch_bounds__(256, 4) void conv3x3_halo16_kernel(const ConvArgs p, const v4f* __restrict__ wfrag, const int tiles_x, const int tiles_y) {
+    constexpr int SLOTS = (CH_HALO * 4 + 255) / 256 * 256;
+    __shared__ v4f halo[SLOTS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, q = lane >> 4;
+    int t;
+    {
+        const int nb = gridDim.x, qq = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+        t = x * qq + min(x, r8) + (int)(blockIdx.x >> 3);
+    }
+    const int tx0 = (t % tiles_x) * CH_TW; t /= tiles_x;
+    const int ty0 = (t % tiles_y) * CH_TH;
+    const int n = t / tiles_y;
+    const float* img = p.in + (size_t)n * p.H * p.W * 16;
+#pragma unroll
+    for (int jj = 0; jj < SLOTS / 256; ++jj) {                      // halo: as conv3x3_halo_kernel (physical column = logical ^ key(hx))
+        const int s = jj * 256 + tid, hp = s >> 2, cp = s & 3;
+        const float* src = p.zeros;
+        if (hp < CH_HALO) {
+            const int hy = hp / CH_HW, hx = hp - hy * CH_HW;
+            const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) src = img + ((size_t)iy * p.W + ix) * 16 + ((cp ^ ((hx >> 2) & 3)) * 4);
+        }
+        halo_dma16(src, halo + jj * 256 + wid * 64);
+    }
+    v4f w[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) w[tap] = wfrag[tap * 64 + lane];  // (issued before the barrier: they arrive while the halo does)
+    v4f acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    __syncthreads();                                               // (drains vmcnt: the halo has landed)
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int hx = j + kx;
+        const int col = q ^ ((hx >> 2) & 3);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const v4f x = halo[((2 * wid + g + ky) * CH_HW + hx) * 4 + col];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[tap][s], x[s], acc[g], 0, 0, 0);
+        }
+    }
+    const int co = 4 * q;
+    if (co >= p.Cout) return;
+    const v4f b4 = *reinterpret_cast<const v4f*>(p.bias + co);
+    const int ox = tx0 + j;
+    v4f r4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    size_t m[2]; bool ok[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {                                   // residual reads before the stores (loads and stores share vmcnt)
+        const int oy = ty0 + 2 * wid + g;
+        ok[g] = oy < p.Ho && ox < p.Wo;
+        m[g] = ((size_t)n * p.Ho + min(oy, p.Ho - 1)) * p.Wo + min(ox, p.Wo - 1);
+        if (p.res) r4[g] = *reinterpret_cast<const v4f*>(p.res + m[g] * p.Cout + co);
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        v4f v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = halo_act(acc[g][c] + b4[c], p.act);
+        v += r4[g];
+        if (ok[g]) *reinterpret_cast<v4f*>(p.out1 + m[g] * p.Cout + co) = v;
+    }
+}
+
 // Can this convolution take the spatial-tile kernel?  (3x3 stride 1 pad 1, Cin = 16, Cout <= 64, ReLU / sigmoid / none, residual of
 // the same shape or none, no second output; maps large enough that 8 x 16 tiles are mostly full)
 bool conv_halo_ok(const ConvArgs& a) {
     return a.ks == 3 && a.stride == 1 && a.pad == 1 && a.Cin == 16 && a.Cout <= 64 && a.act != (int)Act::PRELU && !a.out2 &&
-           (a.res_mode == (int)ResMode::NONE || a.res_mode == (int)ResMode::SAME) && a.H >= 16 && a.W >= 16 && a.dw_w == nullptr && !a.bias_cls;
+           (a.res_mode == (int)ResMode::NONE || a.res_mode == (int)ResMode::SAME) && a.H >= 16 && a.W >= 16 && a.dw_w == nullptr && !a.bias_cls &&
+           !(a.n_outs > 0 && a.Cout <= 16 && (a.Cout & 3) == 0);        // (that shape's weights are packed for the 16x16x4 kernel, which has no merged outputs)
 }
 
-size_t conv_halo_wfrag_floats(int Cin, int Cout) { return (size_t)9 * (Cin / 8) * ((Cout + 31) / 32) * 64 * 4; }
+size_t conv_halo_wfrag_floats(int Cin, int Cout) { return (size_t)9 * (Cin / 8) * ((Cout + 31) / 32) * 64 * 4; }   // (the 16x16x4 form uses the first half)
 
 // host: plan-layout weights [Cout][9][Cin] -> fragment order [tap][k-step s][n-tile j][lane][4]: lane (fr, fh2) holds output channel
 // j*32 + fr, input channels (2s + fh2)*4 .. +3 of that tap (rows >= Cout are zero)
 void conv_halo_pack_weights(const float* w, int Cout, int Cin, float* dst) {
+    if (Cin == 16 && Cout <= 16 && (Cout & 3) == 0) {
+        // conv3x3_halo16_kernel: [tap][lane][4], lane (i = lane & 15, q = lane >> 4) = w[cout i][tap][4q .. 4q+3] (rows >= Cout zero).  A
+        // merged-output convolution of this shape (n_outs > 0) would need the 32x32 layout: conv_halo_ok refuses it.
+        for (int tap = 0; tap < 9; ++tap)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int co = lane & 15, ci = (lane >> 4) * 4;
+                float* d = dst + ((size_t)tap * 64 + lane) * 4;
+                for (int c = 0; c < 4; ++c) d[c] = co < Cout ? w[((size_t)co * 9 + tap) * Cin + ci + c] : 0.f;
+            }
+        return;
+    }
     const int KS = Cin / 8, TN = (Cout + 31) / 32;
     for (int tap = 0; tap < 9; ++tap)
         for (int s = 0; s < KS; ++s)
@@ -206,7 +292,8 @@ void launch_conv_halo(const ConvArgs& a0, const float* wfrag, hipStream_t s) {
     const v4f* wf = reinterpret_cast<const v4f*>(wfrag);
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
-    if (a.Cout <= 32) hipLaunchKernelGGL((conv3x3_halo_kernel<4, 1>), grid, dim3(256), 0, s, a, wf, tiles_x, tiles_y);
+    if (halo16_shape(a.Cin, a.Cout, a.n_outs)) hipLaunchKernelGGL(conv3x3_halo16_kernel, grid, dim3(256), 0, s, a, wf, tiles_x, tiles_y);
+    else if (a.Cout <= 32) hipLaunchKernelGGL((conv3x3_halo_kernel<4, 1>), grid, dim3(256), 0, s, a, wf, tiles_x, tiles_y);
     else hipLaunchKernelGGL((conv3x3_halo_kernel<4, 2>), grid, dim3(256), 0, s, a, wf, tiles_x, tiles_y);
     timer.end(s, 9, a.t_flops, a.t_bytes);
 }

@@ -1203,6 +1203,8 @@ HALO_CASES = [
     (23, 50, 16, 30, False),
     (40, 24, 16, 64, True),
     (33, 17, 16, 40, False),
+    (19, 33, 16, 8, True),            # Cout <= 16: the 16x16x4-MFMA form (conv3x3_halo16_kernel), output channels 8 / 12 of 16 rows live
+    (40, 40, 16, 12, False),
 ]
 
 
