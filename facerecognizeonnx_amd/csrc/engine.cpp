@@ -314,7 +314,8 @@ void Net::reserve(int max_batch) {
 void Net::run_u8(const uint8_t* src, long img_stride, int srcH, int srcW, int step, int batch, hipStream_t s) {
     if (batch <= 0) return;
     if (batch > cap_) throw std::runtime_error("Net::run_u8: batch exceeds reserved capacity");
-    if (stem_ok_ && fuse_stem && front_ok_ && fuse_front) {
+    // (srcW >= 2: front_kernel reads a row-end dword from the row's last four bytes — a one-pixel-wide image has only three)
+    if (stem_ok_ && fuse_stem && front_ok_ && fuse_front && srcW >= 2) {
         // stem conv -> depthwise 3x3 -> pointwise 1x1 in ONE kernel: the stem's 16-channel map (the largest tensor of SCRFD) is never written
         const POp& st = plan_.ops[0];
         const POp& op = plan_.ops[1];
