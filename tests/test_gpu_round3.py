@@ -347,3 +347,31 @@ def test_batch1_graph_replay_is_bitwise_the_eager_path(models_dir):
     orec = oracle.OracleRecognizer(); assert orec.loadModel(util.tiny_iresnet(models_dir))
     f = det.detect_records(imgs[0], 0.5, 0.4)
     assert 1.0 - float(np.dot(rec.extractFeature(imgs[0], f[0]), orec.extractFeature(imgs[0], f[0]))) < 1e-5
+
+
+def test_mixed_winograd_tiling_in_its_three_transform_roles(tmp_path):
+    """14x14 maps at B >= 64 take the mixed F(4x4) / F(2x2) tiling (winograd.hip, WinoPlanes).  One kernel serves three roles: image -> V at the
+    head of a chain, M -> activation -> V between two layers (fusion on), M -> output at the end of a chain and, with the fusion switched
+    off, after EVERY layer.  A small IResNet whose 14x14 stage holds two blocks of 128 channels, B = 64 (planes of 576 / 192 / 64 rows, all
+    padded to whole 128-row GEMM tiles): embeddings vs the oracle in both modes, and the two modes against each other."""
+    torch = pytest.importorskip("torch")
+    path = models.make_iresnet(str(tmp_path / "mix.onnx"), (1, 1, 2, 1), (32, 64, 128, 128), 112, 64, seed=9)
+    rec = fa.FaceRecognizer(); orec = oracle.OracleRecognizer()
+    assert rec.loadModel(path) and orec.loadModel(path)
+    n = 64
+    crops = util.frames_u8(n, 112, 112, seed=31)
+    raws = []
+    try:
+        for fusion in (1, 0):
+            assert fa.lib().fh_rec_set_wino_fusion(rec.handle, fusion) == 0
+            out = torch.zeros((n, 64), device="cuda"); raw = torch.zeros((n, 64), device="cuda")
+            assert rec.embed_aligned_dev(dev(crops).data_ptr(), n, out.data_ptr(), raw.data_ptr()) == n
+            torch.cuda.synchronize()
+            raws.append(raw.cpu().numpy())
+    finally:
+        fa.lib().fh_rec_set_wino_fusion(rec.handle, 1)
+    for i in (0, 17, 63):
+        r = oracle.run_graph(orec.g, {orec.g.inputs[0][0]: oracle.rec_preprocess(crops[i])[None]})[orec.g.outputs[0][0]].reshape(-1)
+        for k, g in enumerate(raws):
+            np.testing.assert_allclose(g[i], r, rtol=2e-4, atol=2e-4 * np.abs(r).max(), err_msg=f"fusion={1 - k} slot {i}")
+    assert np.abs(raws[0] - raws[1]).max() <= 1e-5 * np.abs(raws[0]).max()          # same arithmetic, the activation only takes a different route
