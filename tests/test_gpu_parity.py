@@ -1153,6 +1153,31 @@ def test_det500m_letterboxed_frame_heads_match_oracle():
             np.testing.assert_allclose(got[i][0], ref[i], rtol=1e-4, atol=1e-4, err_msg=f"{rows}x{cols} output {i}")
 
 
+def test_det500m_seeded_random_frame_shapes_and_pitches_match_oracle():
+    """The fused front kernel's window staging (row-end dwords read from a clamped position and shifted into place, letterbox canvas,
+    conv padding patched in on border tiles) on frame shapes nobody picked by hand: 10 seeded (rows, cols) incl. odd widths, shapes
+    that are resized first, and padded row pitches off the dword grid — heads of det_500m vs the oracle."""
+    from facerecognizeonnx_amd.synth import models
+    path = models.cached("det_500m_seed100.onnx", models.make_det_500m)
+    det = fa.FaceDetector(); odet = oracle.OracleDetector()
+    assert det.loadModel(path) and odet.loadModel(path)
+    rng = np.random.default_rng(2026)
+    shapes = [(int(rng.integers(33, 900)), int(rng.integers(33, 900))) for _ in range(8)] + [(640, 639), (639, 640)]
+    for k, (rows, cols) in enumerate(shapes):
+        img = util.frames_u8(1, rows, cols, seed=rows * 7 + cols, smooth=True)
+        pad = int(rng.integers(0, 7)) if k % 2 else 0                    # every other frame: a row pitch with 0..6 bytes of padding
+        step = cols * 3 + pad
+        buf = np.zeros((rows, step), np.uint8); buf[:, :cols * 3] = img[0].reshape(rows, cols * 3)
+        d = dev(buf)
+        assert fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), 1, rows, cols, step, rows * step, 0) == 1
+        torch.cuda.synchronize()
+        got = _det_outputs(det, 1)
+        inp, scale = oracle.det_preprocess(img[0], 640, 640)
+        ref = odet.run_network(inp)
+        for i in range(9):
+            np.testing.assert_allclose(got[i][0], ref[i], rtol=1e-4, atol=1e-4, err_msg=f"{rows}x{cols} step {step} output {i}")
+
+
 def test_fused_front_equals_separate_kernels():
     """Stem conv computed inside the first depthwise -> pointwise kernel (SCRFD's opening block) vs the three-kernel form: same heads
     up to fp32 summation order, on a full frame, a letterboxed frame and a frame with a padded row pitch."""
