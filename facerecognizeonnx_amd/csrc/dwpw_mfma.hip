@@ -361,6 +361,19 @@ constexpr int FR_PITCH = 32;                                               // dw
 constexpr int FR_ROWS = 21;                                                // 9*2 + 3
 constexpr int FR_SLOTS = (FR_ROWS * FR_PITCH + 255) / 256;                 // staged dwords per thread (3)
 
+// Wave priority by tile count, for the persistent kernels below.  A SIMD's instruction arbiter prefers its OLDEST wave: with several
+// persistent workgroups per CU and a static share of tiles each, the first-launched workgroup runs at full speed and the last-launched one
+// on what is left (front_kernel's phase stamps: a workgroup's loop took 586 k / 690 k / 811 k / 936 k cycles by launch order on its CU) —
+// the kernel ends with the slowest while the fast ones' slots idle.  s_setprio beats age, so every workgroup takes each level in turn.
+__device__ __forceinline__ void rotate_wave_priority(int it) {
+    switch (it & 3) {                                                      // (s_setprio takes an immediate)
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would make every barrier of the tile loop
 // wait for the NEXT tile's window loads
 __device__ __forceinline__ void front_barrier() {
@@ -471,7 +484,9 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
 #else
 #define FRONT_STAMP(i)
 #endif
+    int prio_it = (int)(blockIdx.x >> 8);                                  // (launch order on the CU, as far as the dispatcher deals round-robin)
     for (; t < run1; t += wgs, buf ^= 1) {
+        if (!p.no_prio) rotate_wave_priority(prio_it++);                   // (see rotate_wave_priority; no_prio: A / B switch)
 #ifdef FACEHIP_DWPW_PROF
         fst0 = __builtin_readcyclecounter(); ++fnt;
 #endif
@@ -534,7 +549,27 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
             float f[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = 0.f;
-            if (hp >= 0) {
+            if constexpr (STEP4) {
+                // One instruction sequence for all four K blocks (the two-path form below costs a wave BOTH paths: ~100 instructions per
+                // group, a third of them exec-mask bookkeeping): three dword reads — consecutive dwords of window row g (g < 3), or the
+                // dword holding byte 8 in each of the three rows (g = 3: lane-constant stride `kstep`) — and three byte permutes with
+                // per-lane selectors: g < 3: alignbyte twice (+ an identity), g = 3: byte sh of d0 / d1 / d2 into bytes 0 / 1 / 2.  The
+                // g = 3 lanes' bytes 3..7 are whatever the dwords hold — finite u8 values against the ZERO weights of K = 27..31.  Lanes
+                // beyond the halo (hp < 0) read the window's first dwords; their result is never stored.
+                const unsigned pos = (base_lo & 3u) + (unsigned)(hp >= 0 ? g_cb[i] : 0);
+                const unsigned sh = pos & 3u;
+                const int i0 = (hp >= 0 ? g_rq[i] * FR_PITCH : 0) + (int)(pos >> 2);
+                const int kstep = g < 3 ? 1 : FR_PITCH;
+                const unsigned d0 = st[i0], d1 = st[i0 + kstep], d2 = st[i0 + 2 * kstep];
+                const unsigned alsel = 0x03020100u + 0x01010101u * sh;
+                const unsigned selA = g < 3 ? alsel : (sh | ((4u + sh) << 8));
+                const unsigned selC = g < 3 ? 0x03020100u : (0x03000100u | ((4u + sh) << 16));
+                unsigned n0 = __builtin_amdgcn_perm(d1, d0, selA);
+                const unsigned n1 = __builtin_amdgcn_perm(d2, d1, alsel);
+                n0 = __builtin_amdgcn_perm(d2, n0, selC);
+                f[0] = (float)(n0 & 255u); f[1] = (float)((n0 >> 8) & 255u); f[2] = (float)((n0 >> 16) & 255u); f[3] = (float)(n0 >> 24);
+                f[4] = (float)(n1 & 255u); f[5] = (float)((n1 >> 8) & 255u); f[6] = (float)((n1 >> 16) & 255u); f[7] = (float)(n1 >> 24);
+            } else if (hp >= 0) {
                 if (g < 3) {                                                // 8 bytes at an unaligned position: 3 aligned dwords
                     const unsigned pos = ((STEP4 ? base_lo : base_lo + (unsigned)(g_rq[i] * step)) & 3u) + (unsigned)g_cb[i];
                     const unsigned* q = st + g_rq[i] * FR_PITCH + (pos >> 2);
@@ -760,7 +795,9 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 #else
 #define DWPW_STAMP(i)
 #endif
+    int prio_it = (int)(blockIdx.x >> 8);
     for (; t < run1; t += wgs) {
+        if (!p.no_prio) rotate_wave_priority(prio_it++);                   // (oldest-first arbitration vs static tile shares: see rotate_wave_priority)
         const int n = t / per_img, rem = t - n * per_img;
         const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
         const int ty0 = tyi * DP_TH, tx0 = txi * DP_TW;
@@ -893,7 +930,9 @@ static void launch_dwpw_reg_cfg(const ConvArgs& a, hipStream_t s) {
     }
     int grid = std::min((tiles_total + 7) / 8 * 8, cus * OCC);
     grid = std::max(8, grid / 8 * 8);
-    hipLaunchKernelGGL((dwpw_reg_kernel<CQ, TN, OCC, DS>), dim3((unsigned)grid), dim3(256), lds, s, a, tiles_x, tiles_y, tiles_total);
+    ConvArgs ap = a;
+    { static int pr = -1; if (pr < 0) { const char* e = getenv("FACEHIP_DWPW_PRIO"); pr = e ? atoi(e) : 1; } ap.no_prio = pr ? 0 : 1; }   // (0: no priority rotation — A / B timing)
+    hipLaunchKernelGGL((dwpw_reg_kernel<CQ, TN, OCC, DS>), dim3((unsigned)grid), dim3(256), lds, s, ap, tiles_x, tiles_y, tiles_total);
 }
 // true = launched.  Instantiated for SCRFD-500M's stride-1 blocks (C = 16 / 40 / 64 / 72) with any Cout <= 96.
 static bool launch_dwpw_reg(const ConvArgs& a, hipStream_t s) {
@@ -947,8 +986,10 @@ static void launch_front(const ConvArgs& a, hipStream_t s) {
     while (wgs > 1 && (gcd(wgs, tiles_x) != 1 || gcd(wgs, tiles_y) != 1)) --wgs;
     if (wgs * 8 * 10 >= grid * 9) grid = wgs * 8;                           // (only if it costs < 10 % of the workgroups)
     const dim3 g3((unsigned)grid);
-    if (a.u8_step % 4 == 0) hipLaunchKernelGGL(front_kernel<true>, g3, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_total);
-    else hipLaunchKernelGGL(front_kernel<false>, g3, dim3(256), 0, s, a, tiles_x, tiles_y, tiles_total);
+    ConvArgs ap = a;
+    { static int pr = -1; if (pr < 0) { const char* e = getenv("FACEHIP_FRONT_PRIO"); pr = e ? atoi(e) : 1; } ap.no_prio = pr ? 0 : 1; }   // (0: no priority rotation — A / B timing)
+    if (a.u8_step % 4 == 0) hipLaunchKernelGGL(front_kernel<true>, g3, dim3(256), 0, s, ap, tiles_x, tiles_y, tiles_total);
+    else hipLaunchKernelGGL(front_kernel<false>, g3, dim3(256), 0, s, ap, tiles_x, tiles_y, tiles_total);
 }
 
 void launch_dwpw(const ConvArgs& a0, hipStream_t s) {

@@ -75,6 +75,7 @@ struct ConvArgs {
     const float* stem_wf;
     const float* stem_bf;
     const unsigned* stem_wfrag;   // launch_dwpw's fused stem: stem_wf as bf16 MFMA fragments (stem_pack_wfrag)
+    int no_prio;            // 1: the persistent depthwise kernels do not rotate their wave priority (dwpw_mfma.hip rotate_wave_priority: A / B switch)
     int no_pw;              // 1: keep conv_igemm_kernel even where conv_pw_kernel (the lean 1x1 form) would take the layer (forced-cfg runs)
     int n_outs;             // > 0: merged sibling convs — channels [oc0[g], oc0[g+1]) go to outs[g] with act oact[g]
     float* outs[3];

@@ -55,6 +55,20 @@ if len(live):
     wave_tot = live[:, :6].sum(axis=1).astype(np.float64)      # cycles a wave spent in its tile loop: the kernel ends with the SLOWEST one
     print(f"per-wave loop cycles: min {wave_tot.min():.0f}, median {np.median(wave_tot):.0f}, mean {wave_tot.mean():.0f}, max {wave_tot.max():.0f}  "
           f"(max / mean = {wave_tot.max() / wave_tot.mean():.2f})")
+    # where the slow waves sit: per XCD (workgroup id % 8) and per position inside the XCD's run (id // 8)
+    wg_tot = buf[:, :, :6].sum(axis=2).max(axis=1).astype(np.float64)     # slowest wave of each workgroup
+    used = buf[:, 0, 6] > 0
+    ids = np.nonzero(used)[0]
+    if len(ids):
+        per_xcd = [wg_tot[ids[ids % 8 == x]].mean() for x in range(8)]
+        print("per-XCD mean of a workgroup's slowest wave:", " ".join(f"{v:.0f}" for v in per_xcd))
+        pos = ids // 8
+        q = np.quantile(pos, [0.25, 0.5, 0.75])
+        parts = [wg_tot[ids[pos <= q[0]]].mean(), wg_tot[ids[(pos > q[0]) & (pos <= q[1])]].mean(), wg_tot[ids[(pos > q[1]) & (pos <= q[2])]].mean(), wg_tot[ids[pos > q[2]]].mean()]
+        print("by position in the XCD's workgroup list (quartiles):", " ".join(f"{v:.0f}" for v in parts))
+        order = np.argsort(wg_tot[ids])
+        print("slowest 12 workgroups (id, cycles, tiles):", [(int(ids[k]), int(wg_tot[ids[k]]), int(buf[ids[k], 0, 6])) for k in order[-12:]])
+        print("fastest 6 workgroups:", [(int(ids[k]), int(wg_tot[ids[k]]), int(buf[ids[k], 0, 6])) for k in order[:6]])
     mhz = live[:, 7] / 10.0                                     # shader cycles per 100 MHz tick x 100
     print(f"in-kernel shader clock (s_memtime / s_memrealtime over the tile loop): median {np.median(mhz):.0f} MHz, min {mhz.min():.0f}, max {mhz.max():.0f}")
 else:

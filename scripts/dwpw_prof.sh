@@ -7,5 +7,7 @@ B=build/facehip
 cp facerecognizeonnx_amd/libfacehip.so /tmp/libfacehip_backup.so
 OBJS=$(ls $B/*.o | grep -v dwpw_mfma.o | grep -v dwpw_mfma_prof.o)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o facerecognizeonnx_amd/libfacehip.so $OBJS $B/dwpw_mfma_prof.o -lz
-for shape in "80 80 72 72" "160 160 40 40" "80 80 64 64" "320 320 16 16" "320 320 16 40 128 2"; do echo "== $shape"; python scripts/dwpw_prof.py $shape 2>&1 | grep -v amdgpu.ids; done
+SHAPES=("80 80 72 72" "160 160 40 40" "80 80 64 64" "320 320 16 16" "320 320 16 40 128 2")
+if [ -n "$DWPW_PROF_SHAPE" ]; then SHAPES=("$DWPW_PROF_SHAPE"); fi
+for shape in "${SHAPES[@]}"; do echo "== $shape"; python scripts/dwpw_prof.py $shape 2>&1 | grep -v amdgpu.ids; done
 cp /tmp/libfacehip_backup.so facerecognizeonnx_amd/libfacehip.so
