@@ -902,6 +902,188 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 #endif
 }
 
+// ---- stride-2 block with more channels than one halo image can hold (SCRFD: 160x160x40 -> 80x80x72).  A 17 x 33 halo of all 40 channels is
+// 99 KB — one workgroup per CU — so the K loop is split: channels [0, 4 CQA) and [4 CQA, 4 (CQA + CQB)) take turns in ONE halo buffer of
+// 4 CQA channels per pixel (63 KB at CQA = 6: two workgroups per CU).  Per tile: part A's prefetched registers -> LDS, part A's steps, part B's
+// registers -> LDS (same buffer), part B's steps, stores; the accumulators live through both.  Both parts' halos of the NEXT tile are in
+// flight during this tile's work (A from the top of the tile, B from its middle).  Everything else is dwpw_reg_kernel: lane = (pixel, half),
+// depthwise result -> MFMA B fragment, hand-scheduled slots, buffer loads with hardware zero fill, persistent workgroups, priority rotation.
+template <int CQA, int CQB, int TN, int OCC>
+__global__ __launch_bounds__(256, OCC) void dwpw_reg2_kernel(const ConvArgs p, const int tiles_x, const int tiles_y, const int tiles_total) {
+    static_assert(CQA % 2 == 0 && CQB % 2 == 0 && CQB <= CQA, "whole 8-channel MFMA steps per part; part B fits part A's buffer");
+    constexpr int DS = 2, CQ = CQA + CQB, C = CQ * 4, STEPS = C / 8, SA = CQA / 2;
+    constexpr int PQ = CQA + 1;                                            // halo pixel pitch in float4 (odd)
+    constexpr int HH = (DP_TH - 1) * DS + 3, HWD = (DP_TW - 1) * DS + 3, HALO = HH * HWD;   // 17 x 33 = 561
+    constexpr int NPA = (HALO * CQA + 255) / 256, NPB = (HALO * CQB + 255) / 256;
+    extern __shared__ v4f smem[];
+    v4f* const halo = smem;                                                // [HALO][PQ]
+    v4f* const dwl = halo + HALO * PQ;                                     // [10][CQ]: 9 taps + bias
+    v4f* const Wl = dwl + 10 * CQ;                                         // [STEPS][2][Cout]
+    float* const pwb = reinterpret_cast<float*>(Wl + STEPS * 2 * p.Cout);  // [32 * TN]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int Cout = p.Cout;
+    const float dw_floor = p.dw_act == (int)Act::RELU ? 0.f : -INFINITY, out_floor = p.act == (int)Act::RELU ? 0.f : -INFINITY;
+
+    for (int i = tid; i < 10 * CQ; i += 256) {
+        const int k = i / CQ, q = i - k * CQ;
+        dwl[i] = *reinterpret_cast<const v4f*>(k < 9 ? p.dw_w + (size_t)k * C + 4 * q : p.dw_b + 4 * q);
+    }
+    for (int i = tid; i < STEPS * 2 * Cout; i += 256) {
+        const int n = i % Cout, jh = i / Cout;
+        Wl[i] = *reinterpret_cast<const v4f*>(p.wt + (size_t)n * p.Kpad + 4 * jh);
+    }
+    for (int i = tid; i < 32 * TN; i += 256) pwb[i] = i < Cout ? p.bias[i] : 0.f;
+
+    const int pix = wid * 32 + r, py = pix / DP_TW, px = pix - py * DP_TW;
+    const v4f* const hbase = halo + (py * DS * HWD + px * DS) * PQ + h;    // + (ky * HWD + kx) * PQ + 2 (j - first step of the part)
+    const v4f* const dbase = dwl + h;
+    int wrow[TN];
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) wrow[jn] = h * Cout + min(32 * jn + r, Cout - 1);
+
+    const int xcd = blockIdx.x & 7, wg = blockIdx.x >> 3, wgs = gridDim.x >> 3;
+    const int q8 = tiles_total >> 3, r8 = tiles_total & 7;
+    const int run0 = xcd * q8 + min(xcd, r8), run1 = run0 + q8 + (xcd < r8 ? 1 : 0);
+    const int per_img = tiles_x * tiles_y;
+
+    v4f pfa[NPA], pfb[NPB];
+    int voa[NPA], vob[NPB];
+#pragma unroll
+    for (int k = 0; k < NPA; ++k) {
+        const int i = min(tid + 256 * k, HALO * CQA - 1);
+        const int hp = i / CQA, q = i - hp * CQA;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        voa[k] = ((hy * p.W + hx) * C + 4 * q) * 4;
+    }
+#pragma unroll
+    for (int k = 0; k < NPB; ++k) {
+        const int i = min(tid + 256 * k, HALO * CQB - 1);
+        const int hp = i / CQB, q = i - hp * CQB;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        vob[k] = ((hy * p.W + hx) * C + 4 * (CQA + q)) * 4;
+    }
+    const int img_bytes = p.H * p.W * C * 4;
+    // (one part of tile t's halo: global -> registers, issued and not waited for; rows outside the image are out of the descriptor's range and
+    //  read as zero, columns left / right of it are pushed out of range on the first / last tile column)
+#define DWPW2_PREFETCH(PF, VO, NP, CQP, T)                                                                                                  \
+    {                                                                                                                                       \
+        const int n_ = (T) / per_img, rem_ = (T) - n_ * per_img;                                                                            \
+        const int tyi_ = rem_ / tiles_x, txi_ = rem_ - tyi_ * tiles_x;                                                                      \
+        const int y0_ = tyi_ * DP_TH * DS - 1, x0_ = txi_ * DP_TW * DS - 1;                                                                 \
+        const __amdgpu_buffer_rsrc_t rsrc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + (size_t)n_ * p.H * p.W * C), 0, img_bytes, 0x00020000); \
+        const int tile_off_ = (y0_ * p.W + x0_) * C * 4;                                                                                    \
+        int vo_[NP];                                                                                                                        \
+        _Pragma("unroll") for (int k = 0; k < NP; ++k) vo_[k] = tile_off_ + VO[k];                                                          \
+        if (x0_ < 0 || x0_ + HWD > p.W) {                                                                                                   \
+            _Pragma("unroll") for (int k = 0; k < NP; ++k) {                                                                                \
+                const int i = min(tid + 256 * k, HALO * CQP - 1);                                                                           \
+                const int hx = (i / CQP) % HWD;                                                                                             \
+                vo_[k] = (unsigned)(x0_ + hx) < (unsigned)p.W ? vo_[k] : (int)0x80000000;                                                   \
+            }                                                                                                                               \
+        }                                                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < NP; ++k) PF[k] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc_, vo_[k], 0, 0)); \
+    }
+    int t = run0 + wg;
+    if (t < run1) { DWPW2_PREFETCH(pfa, voa, NPA, CQA, t) DWPW2_PREFETCH(pfb, vob, NPB, CQB, t) }
+    front_barrier();
+    int prio_it = (int)(blockIdx.x >> 8);
+    for (; t < run1; t += wgs) {
+        if (!p.no_prio) rotate_wave_priority(prio_it++);
+        const int n = t / per_img, rem = t - n * per_img;
+        const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+        const int ty0 = tyi * DP_TH, tx0 = txi * DP_TW;
+        v16f acc[TN];
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const v4f b = *reinterpret_cast<const v4f*>(pwb + 32 * jn + 8 * g + 4 * h);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[jn][4 * g + c] = b[c];
+            }
+        constexpr int NS = 4 * TN, NT = 10, RA = 3, RING = 4;              // (a ring of 5 spills 34 registers beside the two prefetch sets)
+        // the K loop of one part: steps [J0, J1) of the block, whose channels are columns 2 (j - J0) + h of the halo now in LDS
+        auto kpart = [&](auto j0c, auto j1c) __attribute__((always_inline)) {
+            constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value, NJ = J1 - J0;
+            v4f hv[RING], dv[RING], wq[2];
+            auto issue = [&](int G) __attribute__((always_inline)) {       // LDS reads of the part's tap-slot G = NT * (step - J0) + t
+                const int jl = G / NT, tt = G % NT;
+                if (jl >= NJ) return;
+                dv[G % RING] = dbase[(tt == 0 ? 9 : tt - 1) * CQ + 2 * (J0 + jl)];
+                if (tt > 0) hv[G % RING] = hbase[(((tt - 1) / 3) * HWD + (tt - 1) % 3) * PQ + 2 * jl];
+            };
+            v4f an;
+            auto consume = [&](int G) __attribute__((always_inline)) {
+                if (G / NT >= NJ) return;
+                if (G % NT == 0) an = dv[G % RING]; else an += hv[G % RING] * dv[G % RING];
+            };
+            auto wfrag = [&](int grp) __attribute__((always_inline)) {     // A fragment of (step J0 + grp / TN, column group grp % TN)
+                if (grp < NJ * TN) wq[grp & 1] = Wl[2 * (J0 + grp / TN) * Cout + wrow[grp % TN]];
+            };
+            wfrag(0);
+#pragma unroll
+            for (int G = 0; G < RA; ++G) issue(G);
+#pragma unroll
+            for (int G = 0; G < NT; ++G) { issue(G + RA); consume(G); }
+            v4f a;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = fmaxf(an[e], dw_floor);
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl) {
+                    const int grp = j * TN + sl / 4;
+                    if (sl % 4 == 0) wfrag(grp + 1);
+                    acc[sl / 4] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[grp & 1][sl % 4], a[sl % 4], acc[sl / 4], 0, 0, 0);
+#pragma unroll
+                    for (int G = NT * (j + 1) + sl * NT / NS; G < NT * (j + 1) + (sl + 1) * NT / NS; ++G) { issue(G + RA); consume(G); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        // ---- part A
+        front_barrier();                                                    // every wave is done reading the previous tile's part-B halo
+#pragma unroll
+        for (int k = 0; k < NPA; ++k) {
+            const int i = tid + 256 * k;
+            if (i < HALO * CQA) halo[(i / CQA) * PQ + i % CQA] = pfa[k];
+        }
+        if (t + wgs < run1) DWPW2_PREFETCH(pfa, voa, NPA, CQA, t + wgs)
+        front_barrier();
+        kpart(std::integral_constant<int, 0>{}, std::integral_constant<int, SA>{});
+        // ---- part B (same buffer)
+        front_barrier();                                                    // every wave is done reading part A
+#pragma unroll
+        for (int k = 0; k < NPB; ++k) {
+            const int i = tid + 256 * k;
+            if (i < HALO * CQB) halo[(i / CQB) * PQ + i % CQB] = pfb[k];
+        }
+        if (t + wgs < run1) DWPW2_PREFETCH(pfb, vob, NPB, CQB, t + wgs)
+        front_barrier();
+        kpart(std::integral_constant<int, SA>{}, std::integral_constant<int, STEPS>{});
+        // ---- epilogue: lane = pixel, accumulator quads = 4 consecutive channels
+        const int oy = ty0 + py, ox = tx0 + px;
+        if (oy < p.Ho && ox < p.Wo) {
+            float* __restrict__ orow = p.out1 + (((size_t)n * p.Ho + oy) * p.Wo + ox) * Cout;
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = 32 * jn + 8 * g + 4 * h;
+                    if (co >= Cout) continue;
+                    v4f v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(acc[jn][4 * g + c], out_floor);
+                    *reinterpret_cast<v4f*>(orow + co) = v;
+                }
+        }
+    }
+#undef DWPW2_PREFETCH
+}
+
 // Measured and not kept (round 3): the register-fed form WITHOUT a halo image for the stride-2 blocks (every lane gathers the nine taps of
 // its own pixel straight from memory into the ring registers, no barrier in the tile loop at all): 496 / 369 us against 322 / 255 us
 // of dwpw_kernel<.., 2, .., true> on 320x320x16 -> 160x160x40 / 160x160x40 -> 80x80x72.  With lane = pixel a wave-instruction touches 64
@@ -934,6 +1116,24 @@ static void launch_dwpw_reg_cfg(const ConvArgs& a, hipStream_t s) {
     { static int pr = -1; if (pr < 0) { const char* e = getenv("FACEHIP_DWPW_PRIO"); pr = e ? atoi(e) : 1; } ap.no_prio = pr ? 0 : 1; }   // (0: no priority rotation — A / B timing)
     hipLaunchKernelGGL((dwpw_reg_kernel<CQ, TN, OCC, DS>), dim3((unsigned)grid), dim3(256), lds, s, ap, tiles_x, tiles_y, tiles_total);
 }
+template <int CQA, int CQB, int TN, int OCC>
+static void launch_dwpw_reg2_cfg(const ConvArgs& a, hipStream_t s) {
+    const int tiles_x = (a.Wo + DP_TW - 1) / DP_TW, tiles_y = (a.Ho + DP_TH - 1) / DP_TH;
+    const int tiles_total = a.B * tiles_y * tiles_x;
+    const int cus = a.cus > 0 ? a.cus : conv_num_cus();
+    constexpr int CQ = CQA + CQB;
+    const size_t lds = ((size_t)(7 * 2 + 3) * (15 * 2 + 3) * (CQA + 1) + 10 * CQ + (size_t)(CQ / 2) * 2 * a.Cout) * 16 + (size_t)32 * TN * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&dwpw_reg2_kernel<CQA, CQB, TN, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int grid = std::min((tiles_total + 7) / 8 * 8, cus * OCC);
+    grid = std::max(8, grid / 8 * 8);
+    ConvArgs ap = a;
+    { static int pr = -1; if (pr < 0) { const char* e = getenv("FACEHIP_DWPW_PRIO"); pr = e ? atoi(e) : 1; } ap.no_prio = pr ? 0 : 1; }
+    hipLaunchKernelGGL((dwpw_reg2_kernel<CQA, CQB, TN, OCC>), dim3((unsigned)grid), dim3(256), lds, s, ap, tiles_x, tiles_y, tiles_total);
+}
 // true = launched.  Instantiated for SCRFD-500M's stride-1 blocks (C = 16 / 40 / 64 / 72) with any Cout <= 96.
 static bool launch_dwpw_reg(const ConvArgs& a, hipStream_t s) {
     if (!dwpw_reg_enabled() || a.u8_src || a.Cout % 4 || a.Cout > 96) return false;
@@ -945,7 +1145,9 @@ static bool launch_dwpw_reg(const ConvArgs& a, hipStream_t s) {
         // CU; with 40 channels it would be 99 KB (one workgroup per CU) — those blocks stay with dwpw_kernel
         static int s2 = -1;
         if (s2 < 0) { const char* e = getenv("FACEHIP_DWPW_REG_S2"); s2 = e ? atoi(e) : 1; }
-        if (!s2 || a.Cin != 16 || tn > 2 || a.Ho != (a.H - 1) / 2 + 1 || a.Wo != (a.W - 1) / 2 + 1) return false;
+        if (!s2 || a.Ho != (a.H - 1) / 2 + 1 || a.Wo != (a.W - 1) / 2 + 1) return false;
+        if (a.Cin == 40 && tn == 3) { launch_dwpw_reg2_cfg<6, 4, 3, 2>(a, s); return true; }      // (K split: 24 + 16 channels through one 63 KB halo buffer)
+        if (a.Cin != 16 || tn > 2) return false;
         if (tn == 1) launch_dwpw_reg_cfg<4, 1, 3, 2>(a, s); else launch_dwpw_reg_cfg<4, 2, 3, 2>(a, s);
         return true;
     }
