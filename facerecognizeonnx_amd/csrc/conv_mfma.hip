@@ -1033,6 +1033,15 @@ static void launch_cfg(ConvArgs a, int resident_per_cu, int cfg_tag, hipStream_t
             const size_t lds = ((size_t)rows_a * 8 + 2 * BN * 8) * sizeof(v4f);
             int tall_tiles = (T / St) * St;
             tall_tiles -= tall_tiles % tiles_n;
+            // A matrix-core-bound launch takes as long as its busiest CU has tiles (measured on the Winograd GEMMs), not whole
+            // chip-wide rounds: when the remainder is at most one more tile per CU and a tile is short (< ~30 us of one CU's matrix cores),
+            // running it here costs less than the second launch + fix-up of the split (SCRFD's 80x80 head convolution: 6 400 tiles = 25 per
+            // CU exactly: 329 + 38 us -> 343 us); IResNet's 256x64 tiles (44 us each) keep the split.
+            {
+                const int cus_ = a.cus > 0 ? a.cus : num_cus();
+                const double tile_us = 2.0 * BM * BN * (double)a.Kpad / 0.43e6;      // ~110 TFLOP/s over 256 CUs
+                if (tall_tiles > 0 && T - tall_tiles <= cus_ && tile_us < 30.0) tall_tiles = T;
+            }
             if (lds <= (size_t)(160 / TOCC) * 1024 && tall_tiles > 0) {
                 static bool attr_set = false;
                 if (!attr_set) {

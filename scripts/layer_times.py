@@ -53,7 +53,11 @@ for i in range(per):
         print(f"{t*1e3:9.1f} us             {'fix-up' if tg[i] == 6 else 'winograd transform'}")
         continue
     if tg[i] == 10:                                              # whole tile rounds of the next op in conv_tall_kernel; its remainder follows
-        print(f"{t*1e3:9.1f} us  {fl[i]/t/1e9 if t>0 else 0:7.1f} TF/s  tall   {ops[oi] if oi < len(ops) else ''}  (whole tile rounds)")
+        desc = ops[oi] if oi < len(ops) else ''
+        mm = re.search(r"MMAC ([0-9.]+)", desc)
+        whole = bool(mm) and fl[i] >= 0.999 * 2e6 * float(mm.group(1)) * B      # conv_tall_kernel took every tile: no remainder launch follows
+        print(f"{t*1e3:9.1f} us  {fl[i]/t/1e9 if t>0 else 0:7.1f} TF/s  tall   {desc}  ({'all tiles' if whole else 'whole tile rounds'})")
+        if whole: oi += 1
         continue
     print(f"{t*1e3:9.1f} us  {fl[i]/t/1e9 if t>0 else 0:7.1f} TF/s  cfg{tg[i]}  {ops[oi] if oi < len(ops) else ''}")
     oi += 1
