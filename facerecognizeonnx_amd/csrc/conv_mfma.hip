@@ -796,7 +796,7 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_tall_kernel(const Conv
 // source address only advances by 32 floats per chunk — with a zero-line source for the float4 columns behind K in the last chunk
 // (K % 4 == 0, any remainder), 128 x BN tiles with BN = 96 (N = 288: three exact column tiles) / 64 / 32, and the shared
 // conv_epilogue (bias, ReLU / PReLU, residual incl. the FPN's 2x upsampled one, second output) with its vectors parked in LDS.
-// M % 128 == 0 (whole tiles) and at least one tile per resident slot, else launch_conv keeps the generic kernel and its stream-K.
+// M % 128 == 0 (whole tiles) and at least one tile per CU, else launch_conv keeps the generic kernel and its stream-K.
 template <int BN, int OCC>
 __global__ __launch_bounds__(256, OCC) void conv_pw_kernel(const ConvArgs p, const int tiles_n, const int chunks) {
     constexpr int BM = 128, TN = BN / 32, AL = BM / 32, BL = BN / 32;
@@ -907,7 +907,8 @@ static bool launch_pw(ConvArgs a, hipStream_t s) {
     if (cols(96) * 100 <= a.Cout * 107 && cols(96) <= cols(64)) bn = 96;
     const long tiles = (M / 128) * (cols(bn) / bn);
     const int occ = bn == 96 ? 2 : bn == 64 ? 3 : 4;
-    if (tiles < (long)cus * occ) return false;                              // too few tiles to fill the chip: the generic kernel cuts K
+    (void)occ;
+    if (tiles < (long)cus) return false;                                    // fewer tiles than CUs: the generic kernel cuts K over the chip
     if (bn == 96) launch_pw_cfg<96, 2>(a, M, s);
     else if (bn == 64) launch_pw_cfg<64, 3>(a, M, s);
     else launch_pw_cfg<32, 4>(a, M, s);
@@ -1070,7 +1071,13 @@ static void launch_cfg_tail(ConvArgs a, int resident_per_cu, int cfg_tag, hipStr
     int helpers = 0, owners = 0;
     bool fixup = false;
     a.sk_units = 0; a.sk_q = 1; a.sk_owner_chunks = 0; a.sk_maxp = 1;
-    if (R > 0 && R * 10 <= S * 9 && a.slabs && a.sk_enable) {   // worth it only if the last round is <= 90 % full
+    // (a matrix-core-bound launch ends with its busiest CU: leaving R remainder tiles whole costs (ceil(R / CUs) - R / CUs) tile times of
+    //  imbalance; cutting them over the chip costs a fix-up launch (10-17 us).  Short tiles — SCRFD's 20x20 head convolutions, 11 us —
+    //  stay whole: 31 + 17 us -> 25 us; IResNet's 44 us tiles keep the split.)
+    const int cus_ = a.cus > 0 ? a.cus : num_cus();
+    const double tile_us = 2.0 * BM * BN * (double)a.Kpad / 0.43e6;                  // ~110 TFLOP/s over 256 CUs
+    const bool cheap_whole = ((R + cus_ - 1) / cus_ - (double)R / cus_) * tile_us < 10.0;
+    if (R > 0 && R * 10 <= S * 9 && a.slabs && a.sk_enable && !cheap_whole) {   // worth it only if the last round is <= 90 % full
         // (1) owners + helpers inside the launch
         const int H = S - R;
         const int q_o = (int)(((long)R * chunks + (long)H * sk_margin2() / 2 + S - 1) / S);
