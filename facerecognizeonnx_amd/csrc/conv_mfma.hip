@@ -906,8 +906,6 @@ static bool launch_pw(ConvArgs a, hipStream_t s) {
     if (cols(64) * 100 <= a.Cout * 107) bn = 64;
     if (cols(96) * 100 <= a.Cout * 107 && cols(96) <= cols(64)) bn = 96;
     const long tiles = (M / 128) * (cols(bn) / bn);
-    const int occ = bn == 96 ? 2 : bn == 64 ? 3 : 4;
-    (void)occ;
     if (tiles < (long)cus) return false;                                    // fewer tiles than CUs: the generic kernel cuts K over the chip
     if (bn == 96) launch_pw_cfg<96, 2>(a, M, s);
     else if (bn == 64) launch_pw_cfg<64, 3>(a, M, s);
