@@ -148,15 +148,59 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(det_path, rec_path, frames_np, args, threads=None):
-    """Oracle (CPU restatement) on a bounded sample: 4 threads like the reference (src/face_detector.cpp:10), or `threads`."""
+def traffic_from_profile(workload, kernel):
+    """`roofline.traffic` = HBM-side bytes per launch of `kernel` from the committed counter passes (profiles/traffic.json, written by
+    scripts/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs).  The file carries the fingerprint of
+    the sources it was measured on; when csrc/ has changed since, the number is stale and is NOT reported (null + a warning)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, None
+    from facerecognizeonnx_amd._lib import csrc_fingerprint
+    tj = json.load(open(tpath))
+    src = dict(tj.get("_stamp", {}).get(workload, {}))
+    src["file"] = "profiles/traffic.json"
+    live = csrc_fingerprint()
+    src["csrc_sha16_now"] = live
+    if src.get("csrc_sha16") != live:
+        src["stale"] = True
+        print(f"[bench] profiles/traffic.json [{workload}] was measured on csrc {src.get('csrc_sha16', 'unstamped')}, the tree is {live}: "
+              f"roofline.traffic = null (re-run scripts/profile_round.sh + scripts/summarize_profile.py)", file=sys.stderr, flush=True)
+        return None, src
+    return tj.get(workload, {}).get(kernel), src
+
+
+def cpu_baseline(det_path, rec_path, frames_np, args, threads=None, engine="oracle"):
+    """Bounded CPU sample of the same workload: 4 threads like the reference (src/face_detector.cpp:10), or `threads`.
+    engine "oracle": the C restatement end to end (`kind: port`).  engine "torch": the same pre / post-processing, but the two graphs
+    evaluated by torch.nn.functional on CPU tensors (fp32, oneDNN convolutions) — a proxy for what an optimised CPU engine like the
+    ONNX Runtime CPU EP the reference uses would deliver; it is NOT the reference either."""
     from oracle import oracle
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = min(4, ncpu) if threads is None else threads
     oracle.set_threads(threads)
     od, orc = oracle.OracleDetector(), oracle.OracleRecognizer()
     assert od.loadModel(det_path) and orc.loadModel(rec_path)
-    n = max(1, min(args.cpu_sample_frames, len(frames_np)))
+    if engine == "torch":
+        import torch
+        from oracle import torch_graph
+        prev_threads = torch.get_num_threads()
+        torch.set_num_threads(threads)
+        tdet, trec = torch_graph.TorchGraph(od.g, torch.float32), torch_graph.TorchGraph(orc.g, torch.float32)
+        dname, rname, rout = od.g.inputs[0][0], orc.g.inputs[0][0], orc.g.outputs[0][0]
+
+        def det_net(inp):
+            o = tdet.run({dname: inp[None]})
+            return [o[n] for n, _ in od.g.outputs]
+        od.run_network = det_net
+        orc.embed_aligned = lambda aligned: oracle.l2_normalize(trec.run({rname: oracle.rec_preprocess(aligned)[None]})[rout].reshape(-1))
+        # one untimed unit: oneDNN creates its primitives on first use (1.2 s for the detector graph here, against 25 ms per frame after)
+        if args.workload != "embed":
+            w = od.detect(frames_np[0], args.score_thr, args.nms_thr)
+            if args.workload == "e2e" and len(w):
+                orc.extractFeature(frames_np[0], w[0])
+        else:
+            orc.embed_aligned(frames_np[0])
+    n = max(1, min(args.cpu_sample_frames if engine == "oracle" else 4 * args.cpu_sample_frames, len(frames_np)))
     t0 = time.perf_counter()
     faces = 0
     done = 0
@@ -175,7 +219,7 @@ def cpu_baseline(det_path, rec_path, frames_np, args, threads=None):
         done = i + 1
         el = time.perf_counter() - t0
         if done % 4 == 0 or el > args.cpu_budget_s:
-            print(f"[bench] cpu baseline ({threads} threads): {done}/{n} sample units, {el:.1f} s", file=sys.stderr, flush=True)
+            print(f"[bench] cpu baseline ({engine}, {threads} threads): {done}/{n} sample units, {el:.1f} s", file=sys.stderr, flush=True)
         if el > args.cpu_budget_s:                       # bounded sample: the default run must finish within minutes on any host
             break
     n = done
@@ -185,6 +229,12 @@ def cpu_baseline(det_path, rec_path, frames_np, args, threads=None):
                    f"{args.faces_per_frame} face(s) per frame",
             "embed": f"{n} of the batch's 112x112 crops: preprocess + IResNet-50 + L2-normalise",
             "detect": f"{n} of the batch's 640x640 frames: SCRFD + decode + NMS"}[args.workload]
+    if engine == "torch":
+        torch.set_num_threads(prev_threads)
+        return {"value": faces / dt, "unit": unit, "cores": threads, "threads": threads,
+                "kind": "torch-cpu proxy for the ORT CPU EP, not the reference", "cpu": cpu_model_name(), "host_cores_available": ncpu,
+                "engine": f"torch {torch.__version__} CPU fp32 (torch.nn.functional per ONNX node, no graph fusion), oracle pre / post-processing",
+                "sample": what + f" ({dt:.1f} s)"}
     return {"value": faces / dt, "unit": unit, "cores": threads, "threads": threads, "kind": "port", "cpu": cpu_model_name(), "host_cores_available": ncpu,
             "sample": what + f" ({dt:.1f} s, CPU oracle = restatement of the reference, not ONNX Runtime)"}
 
@@ -583,13 +633,9 @@ def main():
                 # the same launches priced with the direct-form FLOPs of the layers they compute (Winograd GEMMs stand for 4x
                 # their own work; the timer carries that figure in the bytes slot of tag 7)
                 algfl = sum(fl[i] for i in (0, 1, 2, 3, 9, 10, 11)) + by[7]
-                traffic = None
-                tpath = os.path.join(ROOT, "profiles", "traffic.json")     # written by scripts/summarize_profile.py from --pmc runs
-                if os.path.exists(tpath):
-                    tj = json.load(open(tpath))
-                    traffic = tj.get(args.workload, {}).get(CFG_NAMES[dom[3]])
+                traffic, traffic_source = traffic_from_profile(args.workload, CFG_NAMES[dom[3]])
                 out["roofline"] = {"bound": "mfma", "kernel": CFG_NAMES[dom[3]], "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                                   "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                                    "launches": int(dom[2]), "avg_launch_us": 1e3 * dom[0] / dom[2],
                                    "algorithmic_gflop_per_launch": dom[1] / dom[2] / 1e9,
                                    "flops_counted": "executed by the matrix cores (wino_gemm_kernel = the 36 GEMMs of a Winograd F(4x4,3x3) layer, "
@@ -625,6 +671,10 @@ def main():
                           "flops_counted": "3 bf16 products (hi*hi, hi*mid, mid*hi) per f32-equivalent product of the 36 Winograd GEMMs"})
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(det_path, rec_path, host, args)                  # the reference's own setting: 4 threads
+            try:                                             # second leg: an optimised CPU engine's view of the same sample (torch / oneDNN)
+                out["cpu_baseline_torch"] = cpu_baseline(det_path, rec_path, host, args, engine="torch")
+            except Exception as e:  # noqa: BLE001 - the proxy leg must never cost the line
+                out["cpu_baseline_torch"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
             ncpu = out["cpu_baseline"]["host_cores_available"]
             if ncpu > 4:                                     # all cores of this process's CPU share (a GPU box gives 16 per GPU;
                 # more OpenMP threads than that only spin against the cgroup quota)

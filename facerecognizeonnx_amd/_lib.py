@@ -34,6 +34,17 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def csrc_fingerprint() -> str:
+    """sha256 (first 16 hex digits) over the kernel / host sources the library is built from: the stamp that ties a committed counter
+    profile (profiles/traffic.json) to the code it was measured on (bench.py reports `roofline.traffic` only when it still matches)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 _vp, _i, _f, _ll, _d = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_double
 _ip = C.POINTER(C.c_int)
 

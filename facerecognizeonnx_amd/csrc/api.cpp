@@ -105,6 +105,14 @@ struct CallStream {                                         // the handle's own 
     hipStream_t get() { if (!s) FH_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking)); return s; }
     ~CallStream() { if (s) (void)hipStreamDestroy(s); }
 };
+// What a captured call depends on beyond its own arguments: where every internal buffer lives (layout epoch), which kernels the
+// handle's switches select (Net::config_word), the stream-K test hook's kernel arguments, and whether a hand-off time-out has been
+// reported since (the eager path then re-zeroes the Net's counters — a replay would skip that).
+static void graph_env_key(std::vector<long long>& key, const fh::Net& net) {
+    key.push_back((long long)fh::layout_epoch());
+    key.push_back(net.config_word());
+    key.push_back((long long)fh::conv_error_generation() << 32 | fh::conv_debug_generation());
+}
 constexpr int kGraphFaces = 256;                            // records copied back inside the graph; a call with more fetches the rest eagerly
 
 struct fh_det {
@@ -250,7 +258,8 @@ int fh_det_detect(fh_det* d, const uint8_t* bgr, int rows, int cols, int step, f
         fh_face* const h_faces = reinterpret_cast<fh_face*>(static_cast<char*>(d->h_res.p) + 64);
         long long kthr, knms;
         { float f = score_thr; int v; memcpy(&v, &f, 4); kthr = v; f = nms_thr; memcpy(&v, &f, 4); knms = v; }
-        const std::vector<long long> key{rows, cols, step, kthr, knms, max_out, (long long)(size_t)d->img.p, (long long)(size_t)d->out.p};
+        std::vector<long long> key{rows, cols, step, kthr, knms, max_out, (long long)(size_t)d->img.p, (long long)(size_t)d->out.p};
+        graph_env_key(key, d->det.net());
         try {
             d->gcall.run(key, s, [&](hipStream_t st) {
                 FH_HIP(hipMemcpyAsync(d->img.p, d->h_img.p, used, hipMemcpyHostToDevice, st));
@@ -400,7 +409,8 @@ int fh_rec_extract(fh_rec* r, const uint8_t* bgr, int rows, int cols, int step, 
         memcpy(io, face, sizeof(fh_face));
         int* okp = reinterpret_cast<int*>(r->face.as<uint8_t>() + sizeof(fh_face));
         hipStream_t s = r->cs.get();
-        const std::vector<long long> key{rows, cols, step, (long long)(size_t)r->img.p, (long long)(size_t)r->emb.p, (long long)(size_t)r->face.p};
+        std::vector<long long> key{rows, cols, step, (long long)(size_t)r->img.p, (long long)(size_t)r->emb.p, (long long)(size_t)r->face.p};
+        graph_env_key(key, r->rec.net());
         r->gcall.run(key, s, [&](hipStream_t st) {
             FH_HIP(hipMemcpyAsync(r->img.p, r->h_img.p, used, hipMemcpyHostToDevice, st));
             FH_HIP(hipMemcpyAsync(r->face.p, io, sizeof(fh_face), hipMemcpyHostToDevice, st));
@@ -431,7 +441,8 @@ int fh_rec_extract_simple(fh_rec* r, const uint8_t* bgr, int rows, int cols, int
         char* const io = static_cast<char*>(r->h_io.p);
         memcpy(r->h_img.p, bgr, used);
         hipStream_t s = r->cs.get();
-        const std::vector<long long> key{rows, cols, step, (long long)(size_t)r->img.p, (long long)(size_t)r->emb.p};
+        std::vector<long long> key{rows, cols, step, (long long)(size_t)r->img.p, (long long)(size_t)r->emb.p};
+        graph_env_key(key, r->rec.net());
         r->gcall_simple.run(key, s, [&](hipStream_t st) {
             FH_HIP(hipMemcpyAsync(r->img.p, r->h_img.p, used, hipMemcpyHostToDevice, st));
             r->rec.resize_embed_dev(r->img.as<uint8_t>(), 1, rows, cols, step, (long)bytes, r->emb.as<float>(), st);

@@ -977,7 +977,10 @@ bool conv_take_error(std::string& msg) {
     return true;
 }
 unsigned conv_error_generation() { return g_sk_generation; }
+static unsigned g_sk_debug_gen = 0;
+unsigned conv_debug_generation() { return g_sk_debug_gen; }
 void conv_debug_streamk(int drop_publish, int timeout_ms) {
+    ++g_sk_debug_gen;
     g_sk_test_drop = drop_publish;
     g_sk_timeout = (unsigned)(((unsigned long long)(timeout_ms > 0 ? timeout_ms : 2000) * 100000ull) >> 16);
 }

@@ -1,6 +1,7 @@
 // engine.cpp — weight upload, arena management and the launch sequences of the face path.
 #include "engine.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -13,11 +14,18 @@ void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(e) + " in " + what);
 }
 
+// Layout epoch: a captured HIP graph (api.cpp, GraphCall) holds the device addresses of every buffer its kernels touched — the
+// arena, the Winograd workspaces, candidate / key / crop buffers — not only the staging buffers of the call that captured it.
+// Any (re)allocation or release of a DevBuf in the process makes such a graph suspect, so the epoch is part of every graph key.
+static std::atomic<unsigned long long> g_layout_epoch{1};
+unsigned long long layout_epoch() { return g_layout_epoch.load(std::memory_order_relaxed); }
+
 DevBuf::~DevBuf() {
-    if (p) (void)hipFree(p);
+    if (p) { (void)hipFree(p); g_layout_epoch.fetch_add(1, std::memory_order_relaxed); }
 }
 void DevBuf::ensure(size_t n) {
     if (n <= bytes) return;
+    g_layout_epoch.fetch_add(1, std::memory_order_relaxed);
     if (p) { FH_HIP(hipDeviceSynchronize()); FH_HIP(hipFree(p)); p = nullptr; bytes = 0; }
     FH_HIP(hipMalloc(&p, n));
     bytes = n;

@@ -26,6 +26,8 @@ struct DevBuf {                // owning hipMalloc buffer
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+unsigned long long layout_epoch();   // bumped by every DevBuf (re)allocation / release in the process (key of captured graphs)
+
 // One ONNX graph planned for a fixed input size, resident on the current device.
 class Net {
   public:
@@ -54,6 +56,13 @@ class Net {
     int cus = 0;                                          // CUs of the stream this net runs on when it is CU-masked (0 = all)
     int force_cfg = -1;                                   // tuning hook: conv tile config override
     bool sk_enable = true;                                // tuning hook: stream-K remainder wave
+    // every switch above that changes which kernels run or with which arguments, as one word: part of the key of a captured
+    // batch-1 graph (api.cpp), so a setter between two calls can never be answered by a replay of the old launch sequence
+    long long config_word() const {
+        return (long long)fuse_stem | (long long)fuse_front << 1 | (long long)winograd << 2 | (long long)halo_conv << 3 |
+               (long long)fold_shortcut << 4 | (long long)fuse_wino << 5 | (long long)bf16x2_ << 6 | (long long)sk_enable << 7 |
+               (long long)(cus & 0xffff) << 8 | (long long)((force_cfg + 1) & 0xff) << 24;
+    }
 
   private:
     struct DevOp {

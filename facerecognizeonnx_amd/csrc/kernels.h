@@ -113,6 +113,7 @@ unsigned* conv_error_words();
 bool conv_take_error(std::string& msg);
 unsigned conv_error_generation();
 void conv_debug_streamk(int drop_publish, int timeout_ms);
+unsigned conv_debug_generation();             // bumped by conv_debug_streamk (its settings are kernel arguments: captured graphs hold them)
 const float* conv_zero_line();                // 8 KiB of device zeros (target of padded / dead loads)
 int conv_num_cus();                           // compute units of the current device
 // dense 3x3 stride-1 convolutions with 16 input channels and <= 64 output channels on an 8x16 spatial tile with an LDS halo

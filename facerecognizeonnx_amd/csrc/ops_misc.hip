@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 #pragma unroll
         for (int o = 0; o < STRIP; ++o) acc[o] = b4;
         const int iy0 = oy0 * STRIDE - 1, ix0 = ox * STRIDE - 1;
-        // UNCONDITIONAL loads from clamped coordinates, zeroed by a multiply afterwards: a load under a branch is waited for at the
+        // UNCONDITIONAL loads from clamped coordinates, zeroed by a select afterwards: a load under a branch is waited for at the
         // branch's join — three latency chains of ROWS loads per thread instead of 3 x ROWS loads in flight (same rule as wino_input_kernel)
         const float* imgp = in + (size_t)n * H * W * C + c4 * 4;
 #pragma unroll
@@ -72,8 +72,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const float* __restrict_
 #pragma unroll
             for (int ridx = 0; ridx < ROWS; ++ridx) {
                 const int iy = iy0 + ridx;
-                const float okf = okx && (unsigned)iy < (unsigned)H ? 1.f : 0.f;
-                x[ridx] = *reinterpret_cast<const v4f*>(imgp + ((size_t)min(max(iy, 0), H - 1) * W + ixc) * C) * okf;
+                const bool ok = okx && (unsigned)iy < (unsigned)H;
+                const v4f ld = *reinterpret_cast<const v4f*>(imgp + ((size_t)min(max(iy, 0), H - 1) * W + ixc) * C);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[ridx][e] = ok ? ld[e] : 0.f;   // a select (v_cndmask), not a multiply: the clamped neighbour may be Inf / NaN
             }
 #pragma unroll
             for (int o = 0; o < STRIP; ++o)
@@ -129,8 +131,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_hstrip_kernel(const float* __re
 #pragma unroll
             for (int cidx = 0; cidx < COLS; ++cidx) {
                 const int ix = ix0 + cidx;
-                const float okf = oky && (unsigned)ix < (unsigned)W ? 1.f : 0.f;
-                x[cidx] = *reinterpret_cast<const v4f*>(rowp + (size_t)min(max(ix, 0), W - 1) * C) * okf;
+                const bool ok = oky && (unsigned)ix < (unsigned)W;
+                const v4f ld = *reinterpret_cast<const v4f*>(rowp + (size_t)min(max(ix, 0), W - 1) * C);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[cidx][e] = ok ? ld[e] : 0.f;
             }
 #pragma unroll
             for (int o = 0; o < STRIP; ++o)

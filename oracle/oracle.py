@@ -2,7 +2,7 @@
 
 PARITY WITH ORT / OPENCV IS UNPINNED: neither library nor a model file exists offline and
 the reference has no golden vectors.  This restatement is pinned by
-hand-derived KATs and by an independent PyTorch-CPU fp64 evaluation (tests/torch_ref.py).
+hand-derived KATs and by an independent PyTorch-CPU fp64 evaluation (oracle/torch_graph.py).
 
 `OracleDetector` / `OracleRecognizer` restate reference `FaceDetector` / `FaceRecognizer`
 (src/face_detector.cpp, src/face_recognizer.cpp): same method names, same error behaviour

@@ -1,7 +1,9 @@
-"""Independent evaluation of the ONNX graphs with PyTorch-CPU (fp64 by default).
+"""Independent evaluation of the ONNX graphs with PyTorch-CPU (test infrastructure, like everything under oracle/).
 
-Used only to pin the oracle; PyTorch is not a reference implementation
-and none of this is on the product path.
+Two users: (1) the tests pin the oracle's graph evaluation against it in fp64; (2) bench.py's second CPU leg
+(`cpu_baseline_torch`) times the two graphs in fp32 on 4 threads as a PROXY for what an optimised CPU engine such as the ONNX
+Runtime CPU EP (the reference's engine, src/face_detector.cpp:10-11) delivers — oneDNN convolutions instead of the oracle's
+naive loops.  PyTorch is not a reference implementation and none of this is on the product path.
 """
 from __future__ import annotations
 
@@ -12,11 +14,26 @@ import torch.nn.functional as F
 from oracle import onnx_min
 
 
+class TorchGraph:
+    """One loaded graph with its initializers converted once (the 174 MB of w600k_r50 are not re-wrapped per call)."""
+
+    def __init__(self, path_or_graph, dtype=torch.float64):
+        self.g = onnx_min.load(path_or_graph) if isinstance(path_or_graph, str) else path_or_graph
+        self.dtype = dtype
+        self.inits = {k: (torch.from_numpy(np.asarray(v)).to(dtype) if v.dtype.kind == "f" else torch.from_numpy(np.asarray(v)))
+                      for k, v in self.g.inits.items()}
+
+    def run(self, feeds: dict) -> dict:
+        with torch.no_grad():
+            return _run(self.g, self.inits, feeds, self.dtype)
+
+
 def run_graph(path_or_graph, feeds: dict, dtype=torch.float64) -> dict:
-    g = onnx_min.load(path_or_graph) if isinstance(path_or_graph, str) else path_or_graph
-    env = {}
-    for k, v in g.inits.items():
-        env[k] = torch.from_numpy(np.asarray(v)).to(dtype) if v.dtype.kind == "f" else torch.from_numpy(np.asarray(v))
+    return TorchGraph(path_or_graph, dtype).run(feeds)
+
+
+def _run(g, inits, feeds, dtype) -> dict:
+    env = dict(inits)
     for k, v in feeds.items():
         env[k] = torch.from_numpy(np.asarray(v)).to(dtype)
     for n in g.nodes:

@@ -12,7 +12,8 @@ message.  It becomes active only when the person running it supplies, in the BUI
 It never downloads anything, never imports or reads anything under /root/reference, and ships no reference code: it calls the same
 two third-party libraries the reference calls, with the reference's own call parameters, on seeded inputs, and writes
 
-    tests/golden/ref_opencv.npz   cv2.resize (INTER_LINEAR), cv2.warpAffine, cv2.estimateAffinePartial2D on seeded inputs
+    tests/golden/ref_opencv.npz   cv2.resize (INTER_LINEAR), cv2.warpAffine, cv2.estimateAffinePartial2D on seeded inputs and on the
+                                  committed equal-count tie cases (tests/golden/consensus_ties.npz)
                                   (needs cv2 only — pins the fixed-point restatements of SURVEY.md App. B)
     tests/golden/ref_det.npz      ORT CPU outputs of det_500m on seeded 640x640 frames preprocessed as face_detector.cpp:92-137
     tests/golden/ref_rec.npz      ORT CPU outputs of w600k_r50 on seeded 112x112 crops preprocessed as face_recognizer.cpp:135-150
@@ -79,6 +80,19 @@ def opencv_goldens(cv2):
         oks.append(M is not None)
         Ms.append(M if M is not None else np.zeros((2, 3)))
         crops.append(cv2.warpAffine(img, M, (112, 112)) if M is not None else np.zeros((112, 112, 3), np.uint8))
+    # equal-count consensus ties between DIFFERENT inlier sets (tests/golden/consensus_ties.npz, generator beside it): the one place
+    # where this build's "most inliers, then the first pair in (i < j) order" and OpenCV's fixed-seed sample order may disagree.
+    # cv2's own M / inlier mask for exactly those landmarks settles it (tests/test_reference_goldens.py compares).
+    ties = os.path.join(GOLDEN, "consensus_ties.npz")
+    if os.path.isfile(ties):
+        tl = np.load(ties)["landmarks"]
+        tM, tin, tok = [], [], []
+        for lm in tl:
+            M, inl = cv2.estimateAffinePartial2D(lm, TEMPLATE)
+            tok.append(M is not None)
+            tM.append(M if M is not None else np.zeros((2, 3)))
+            tin.append(np.asarray(inl).reshape(-1) if inl is not None else np.zeros(5, np.uint8))
+        out["tie_lm"] = tl; out["tie_M"] = np.stack(tM); out["tie_inliers"] = np.stack(tin); out["tie_ok"] = np.array(tok)
     out["warp_lm"] = np.stack(lms); out["warp_M"] = np.stack(Ms); out["warp_crop"] = np.stack(crops); out["warp_ok"] = np.array(oks)
     np.savez_compressed(os.path.join(GOLDEN, "ref_opencv.npz"), **out)
     print(f"[make_reference_goldens] wrote tests/golden/ref_opencv.npz (OpenCV {cv2.__version__})")

@@ -6,6 +6,8 @@ shift || true
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# stamp: which sources these counters were measured on (bench.py drops roofline.traffic when csrc/ has changed since)
+(cd $R && python3 -c "import json,time,sys; sys.path.insert(0,'.'); from facerecognizeonnx_amd._lib import csrc_fingerprint as f; print(json.dumps({'csrc_sha16': f(), 'date': time.strftime('%Y-%m-%dT%H:%M:%SZ', time.gmtime())}))" > $OUT/stamp.json)
 cd /tmp && export TMPDIR=/tmp
 # --serial on the stats leg: with the default two-stream streaming form the detector and recogniser kernels time-share the chip, which
 # stretches every kernel's duration; the roofline's avg launch duration (bench.py's instrumented pass) is of the kernel alone.

@@ -81,6 +81,21 @@ with open(os.path.join(dst, f"{tag}_traffic.csv"), "w") as f:
 tj_path = os.path.join(dst, "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
 tj[workload] = traffic
+# provenance of this workload's numbers: the sources they were measured on (stamp written on the GPU box by profile_round.sh) and the
+# commit checked out here when they were summarised; bench.py copies it into roofline.traffic_source and reports traffic = null when
+# csrc/ no longer hashes to csrc_sha16
+stamp = {}
+sp = os.path.join(src, "stamp.json")
+if os.path.exists(sp):
+    stamp = json.load(open(sp))
+try:
+    import subprocess
+    stamp["commit_at_summary"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    stamp["csrc_dirty_at_summary"] = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "facerecognizeonnx_amd/csrc"], text=True).strip())
+except Exception:  # noqa: BLE001 - no git here: the source hash alone is the stamp
+    pass
+stamp["profile_tag"] = tag
+tj.setdefault("_stamp", {})[workload] = stamp
 tj["_note"] = ("bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 / launches, from separate rocprofv3 --pmc passes "
                "(scripts/profile_round.sh); L2 fabric-side traffic, Infinity-Cache hits included")
 json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)

@@ -4,7 +4,7 @@
 
 * tiny_iresnet.onnx / tiny_scrfd.onnx : seeded synthetic graphs (facerecognizeonnx_amd.synth)
 * *_io.npz : seeded inputs and the graph outputs evaluated INDEPENDENTLY of the oracle and of the
-  product, with PyTorch-CPU in float64 (tests/torch_ref.py).  They pin the oracle's graph
+  product, with PyTorch-CPU in float64 (oracle/torch_graph.py).  They pin the oracle's graph
   operators; the reference itself has no golden vectors and cannot run here.
 """
 import os
@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from facerecognizeonnx_amd.synth import models  # noqa: E402
-from tests import torch_ref  # noqa: E402
+from oracle import torch_graph as torch_ref  # noqa: E402
 
 
 def main():

@@ -92,7 +92,7 @@ def test_planner_folds_dynamic_shape_subgraphs(models_dir):
     """Dynamic-axes exports size their Resize with Shape -> Slice -> Concat sub-graphs (what the public det_500m.onnx
     is expected to contain): with the input size fixed at load time the planner folds them to constants."""
     from oracle import onnx_min, oracle
-    from tests import torch_ref
+    from oracle import torch_graph as torch_ref
     dyn = models.make_scrfd(os.path.join(models_dir, "s_dynresize.onnx"), (1, 2, 1, 2), (8, 8, 16, 24, 32, 48), 8, 16, seed=2,
                             cls_bias=-2.0, dynamic_resize=True)
     ref = util.tiny_scrfd(models_dir, hw=None)
@@ -208,7 +208,7 @@ def _affine_graph(path, H=24, W=20, C=12, Cout=8):
 def test_planner_folds_constant_mul_add_sub_div(tmp_path):
     import facerecognizeonnx_amd as fa
     from oracle import oracle
-    from tests import torch_ref
+    from oracle import torch_graph as torch_ref
     path = _affine_graph(str(tmp_path / "affine.onnx"))
     desc = fa.plan_describe(path, 24, 20)
     assert desc.splitlines()[0].split("ops ")[1].startswith("2 ")          # everything folded into the two convolutions
@@ -225,7 +225,8 @@ def test_mobilefacenet_plans_and_oracle_matches_fp64(models_dir):
     import facerecognizeonnx_amd as fa
     from facerecognizeonnx_amd.synth import models
     from oracle import oracle
-    from tests import torch_ref, util
+    from oracle import torch_graph as torch_ref
+    from tests import util
     full = fa.plan_describe(models.cached("w600k_mbf_seed300.onnx", models.make_w600k_mbf), 112, 112)
     head = full.splitlines()[0]
     assert "ops 50" in head and 0.40 < float(head.split("GMAC/image ")[1].split()[0]) < 0.47      # MobileFaceNet: ~0.44 GMAC
