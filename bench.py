@@ -37,7 +37,8 @@ BF16_MFMA_PEAK_TFLOPS = 2516.8    # the same table: BF16 MFMA = 16x the f32 matr
 CFG_NAMES = ["conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<256,64,4,1>", "conv_igemm_kernel<128,32,4,1>",
              "conv_igemm_kernel<64,64,2,2>", "dwpw_kernel (incl. the fused stem front) + dwconv3x3 kernels", "other graph ops (incl. stem_conv_u8)",
              "conv_fixup_kernel", "wino_gemm_kernel<64, 3>", "wino_input_kernel + wino_output_kernel + wino_fused_kernel + wino_mix_kernel",
-             "conv3x3_halo_kernel", "conv_tall_kernel<256,64,4,1> / <128,32,4,1>", "conv_pw_kernel<96|64|32>"]
+             "conv3x3_halo_kernel", "conv_tall_kernel<256,64,4,1> / <128,32,4,1>", "conv_pw_kernel<96|64|32>",
+             "wino2_kernel<7|8> (fused F(2x2,3x3))"]
 NTAGS = len(CFG_NAMES)
 
 
@@ -624,15 +625,15 @@ def main():
                                                                      if args.gallery and world > 1 else "no data-path collective")},
         }
         if timing:
-            conv = [(ms[i], fl[i], ln[i], i) for i in (0, 1, 2, 3, 7, 9, 10, 11) if ln[i] > 0]
+            conv = [(ms[i], fl[i], ln[i], i) for i in (0, 1, 2, 3, 7, 9, 10, 11, 12) if ln[i] > 0]
             if conv:
                 dom = max(conv)
                 tf = dom[1] / (dom[0] * 1e-3) / 1e12
                 # fix-up and Winograd-transform time counts against the convs; FLOPs = what the matrix cores EXECUTE
                 allms, allfl = sum(c[0] for c in conv) + ms[6] + ms[8], sum(c[1] for c in conv)
                 # the same launches priced with the direct-form FLOPs of the layers they compute (Winograd GEMMs stand for 4x
-                # their own work; the timer carries that figure in the bytes slot of tag 7)
-                algfl = sum(fl[i] for i in (0, 1, 2, 3, 9, 10, 11)) + by[7]
+                # their own work, fused F(2x2) launches for 2.25x; the timer carries that figure in the bytes slot of tags 7 / 12)
+                algfl = sum(fl[i] for i in (0, 1, 2, 3, 9, 10, 11)) + by[7] + by[12]
                 traffic, traffic_source = traffic_from_profile(args.workload, CFG_NAMES[dom[3]])
                 out["roofline"] = {"bound": "mfma", "kernel": CFG_NAMES[dom[3]], "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS,
                                    "unit": "TFLOP/s", "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,

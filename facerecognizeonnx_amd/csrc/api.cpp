@@ -643,7 +643,7 @@ int fh_topk_merge_dev(const float* ps, const int* pi, int nparts, int nq, int k,
 // ---------------------------------------------------------------------------------- timing / tuning
 int fh_timing_enable(int on) { fh::KernelTimer::get().enabled = on != 0; return FH_OK; }
 int fh_timing_collect(double* ms, double* flops, double* bytes, long long* launches, int n) {
-    if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need 12-entry arrays");
+    if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need 13-entry arrays");
     return guarded([&] { fh::KernelTimer::get().collect(ms, flops, bytes, launches); return fh::KernelTimer::kTags; });
 }
 int fh_timing_collect_ops(double* ms, double* flops, int* tag, int cap) {
@@ -776,6 +776,27 @@ int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi, const float* d_
         a.act = (int)fh::Act::NONE; a.res_mode = (int)fh::ResMode::NONE;
         fh::launch_conv_winograd(a, dU.as<float>(), dV.as<float>(), dM.as<float>(), 2, nullptr, nullptr, S(stream));
         FH_HIP(hipStreamSynchronize(S(stream)));                 // the workspaces die with this scope
+        return 0;
+    });
+}
+// Fused Winograd F(2x2,3x3) form (conv_wino2.hip) of one 3x3 stride-1 pad-1 convolution, for the parity tests: w_ohwi = host weights
+// [cout][3*3][cin]; d_bias [cout] or, with bias_cls, [9][cout]; act = fh::Act; d_slope / d_res optional
+int fh_conv_wino2_dev(const float* d_in, const float* w_ohwi, const float* d_bias, const float* d_slope, const float* d_res, float* d_out,
+                      int batch, int h, int w, int cin, int cout, int act, int bias_cls, void* stream) {
+    if (!d_in || !w_ohwi || !d_out || cin % 32 || cout % 64) return arg_error("fh_conv_wino2_dev: bad argument");
+    return guarded([&] {
+        std::vector<float> u(fh::wino2_weight_floats(cin, cout));
+        fh::wino2_pack_weights(w_ohwi, cout, cin, u.data());
+        fh::DevBuf dU;
+        dU.ensure(u.size() * sizeof(float));
+        FH_HIP(hipMemcpy(dU.p, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
+        fh::ConvArgs a{};
+        a.in = d_in; a.wt = dU.as<float>(); a.bias = d_bias; a.slope = d_slope; a.res = d_res; a.out1 = d_out;
+        a.B = batch; a.H = h; a.W = w; a.Ho = h; a.Wo = w; a.Cin = cin; a.Cout = cout; a.ks = 3; a.stride = 1; a.pad = 1;
+        a.act = act; a.bias_cls = bias_cls; a.res_mode = d_res ? (int)fh::ResMode::SAME : (int)fh::ResMode::NONE;
+        fh::launch_wino2(a, S(stream));
+        FH_HIP(hipGetLastError());
+        FH_HIP(hipStreamSynchronize(S(stream)));                 // the weight image dies with this scope
         return 0;
     });
 }

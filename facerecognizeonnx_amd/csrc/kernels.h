@@ -15,7 +15,7 @@ void hip_check(hipError_t e, const char* what);
 // Optional per-launch HIP-event timing of the network kernels (bench.py's roofline leg).
 // Tags: 0..3 = conv_igemm tile configs, 4 = depthwise conv, 5 = other graph ops, 6 = conv stream-K fix-up.
 struct KernelTimer {
-    static constexpr int kTags = 12;     // 0-3 conv tile configs, 4 dw / dwpw, 5 other, 6 fix-up, 7 Winograd GEMM, 8 Winograd transforms, 9 halo conv, 10 conv_tall_kernel, 11 conv_pw_kernel
+    static constexpr int kTags = 13;     // 0-3 conv tile configs, 4 dw / dwpw, 5 other, 6 fix-up, 7 Winograd GEMM, 8 Winograd transforms, 9 halo conv, 10 conv_tall_kernel, 11 conv_pw_kernel, 12 wino2_kernel
     bool enabled = false;
     void begin(hipStream_t s);
     void end(hipStream_t s, int tag, double flops, double bytes);
@@ -114,6 +114,12 @@ bool conv_take_error(std::string& msg);
 unsigned conv_error_generation();
 void conv_debug_streamk(int drop_publish, int timeout_ms);
 unsigned conv_debug_generation();             // bumped by conv_debug_streamk (its settings are kernel arguments: captured graphs hold them)
+// Fused Winograd F(2x2, 3x3) for 3x3 stride-1 pad-1 convolutions with Cin % 32 == 0, Cout % 64 == 0 (conv_wino2.hip): a.wt = the
+// wino2_pack_weights image of the filter [Cout][9][Cin]; epilogue fields (bias / bias_cls, act, slope, res, out1, out2) as for launch_conv
+size_t wino2_weight_floats(int Cin, int Cout);
+void wino2_pack_weights(const float* w_ohwi, int Cout, int Cin, float* dst);
+bool wino2_ok(const ConvArgs& a);
+void launch_wino2(const ConvArgs& a, hipStream_t s);
 const float* conv_zero_line();                // 8 KiB of device zeros (target of padded / dead loads)
 int conv_num_cus();                           // compute units of the current device
 // dense 3x3 stride-1 convolutions with 16 input channels and <= 64 output channels on an 8x16 spatial tile with an LDS halo

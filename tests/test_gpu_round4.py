@@ -194,3 +194,55 @@ def test_align_equal_count_consensus_ties_match_oracle_bit_exact(models_dir):
     half = n // 2
     same = sum(np.array_equal(crops[i], crops[half + i]) or np.abs(crops[i].astype(int) - crops[half + i]).max() <= 1 for i in range(half))
     assert same == half, same                       # the tiny perturbation never flips the chosen model
+
+
+WINO2_CASES = [
+    # B, H,   W,   Cin, Cout, act (0 none / 1 relu / 2 prelu), residual, 9 bias classes
+    (2, 56, 56, 64, 64, 2, True, True),        # IResNet stage 1 shape: 7-wide tile groups (28 tile columns), PReLU + residual, folded BatchNorm
+    (1, 112, 112, 64, 64, 2, False, True),     # the first block's conv: 8-wide tile groups (56 tile columns)
+    (3, 56, 56, 64, 128, 0, False, False),     # two column tiles
+    (5, 13, 17, 32, 64, 1, True, False),       # odd map: ragged tile groups in x and y, one 32-channel chunk, an odd number of groups
+    (2, 30, 22, 96, 64, 2, True, True),        # three chunks; 11 tile columns -> 8-wide groups with a half-empty second group
+    (1, 2, 2, 64, 64, 0, False, True),         # a single tile
+    (4, 80, 80, 64, 64, 1, False, False),      # SCRFD's head map size
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,with_res,cls", WINO2_CASES)
+def test_wino2_fused_conv_layer_matches_oracle(B, H, W, Cin, Cout, act, with_res, cls):
+    """The fused Winograd F(2x2,3x3) kernel (conv_wino2.hip) that takes the 3x3 stride-1 convolutions of w600k_r50's 64-channel stages
+    (Conv nodes inside session_->Run, face_recognizer.cpp:279-283) against the oracle's direct fp32 convolution: bias per border class
+    (the block's BatchNorm folded in), PReLU / ReLU, residual.  5e-5 absolute on O(1) outputs: F(2x2) rounds ~3x coarser than the direct
+    form's 2e-5 bar (points 0, +-1, inf), far inside F(4x4)'s 2e-4."""
+    rng = np.random.default_rng(B * 1000 + H * 10 + Cin + Cout)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    ref = oracle.conv2d(x, w, None, 1, 1, 1)                               # NCHW, no bias
+    if cls:
+        b9 = rng.standard_normal((9, Cout)).astype(np.float32)
+        ys = np.ones(H, int); ys[0] = 0; ys[-1] = 2 if H > 1 else 0
+        xs = np.ones(W, int); xs[0] = 0; xs[-1] = 2 if W > 1 else 0
+        ref = ref + b9[3 * ys[:, None] + xs[None, :]].transpose(2, 0, 1)[None]
+        bias = b9
+    else:
+        bias = rng.standard_normal(Cout).astype(np.float32)
+        ref = ref + bias[None, :, None, None]
+    slope = (0.25 * rng.uniform(0.5, 1.5, Cout)).astype(np.float32)
+    if act == 1:
+        ref = np.maximum(ref, 0)
+    elif act == 2:
+        ref = np.where(ref >= 0, ref, ref * slope[None, :, None, None])
+    res = rng.standard_normal((B, H, W, Cout)).astype(np.float32) if with_res else None
+    if with_res:
+        ref = ref + res.transpose(0, 3, 1, 2)
+    xd, bd, sd = dev(x.transpose(0, 2, 3, 1)), dev(bias), dev(slope)
+    rd = dev(res) if with_res else None
+    w_ohwi = np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(Cout, 9, Cin))
+    out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+    rc = fa.lib().fh_conv_wino2_dev(xd.data_ptr(), w_ohwi.ctypes.data, bd.data_ptr(), sd.data_ptr(), rd.data_ptr() if with_res else 0,
+                                    out.data_ptr(), B, H, W, Cin, Cout, act, 1 if cls else 0, 0)
+    assert rc == 0, fa._lib.last_error()
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().transpose(0, 3, 1, 2)
+    assert not np.isnan(got).any()
+    np.testing.assert_allclose(got, ref.astype(np.float32), rtol=0, atol=5e-5)
