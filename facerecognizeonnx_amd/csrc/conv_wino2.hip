@@ -347,6 +347,12 @@ bool wino2_ok(const ConvArgs& a) {
            (a.res_mode == (int)ResMode::NONE || a.res_mode == (int)ResMode::SAME);
 }
 
+long wino2_blocks(const ConvArgs& a) {
+    const int tgc = pick_tgc(a.W);
+    const long n_tg = (long)a.B * (((a.H + 1) / 2 + 3) / 4) * (((a.W + 1) / 2 + tgc - 1) / tgc);
+    return (n_tg + 1) / 2 * (a.Cout / 64);
+}
+
 // a.wt = wino2_pack_weights' image of the filter; everything else as for launch_conv
 void launch_wino2(const ConvArgs& a_in, hipStream_t s) {
     if (!wino2_ok(a_in)) throw std::runtime_error("launch_wino2: layer shape not supported");

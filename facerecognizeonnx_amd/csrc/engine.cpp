@@ -86,6 +86,15 @@ static bool debug_sync() {
 // 10.6 ms with >= 64: below 128 the two transform passes cost what the matrix cores save)
 static constexpr int kWinoMinCin = 128;
 static constexpr long kWinoMinTiles = 256;      // 4x4-output tiles per launch below which the direct form is used
+static long wino2_min_blocks() {                // workgroups per launch below which conv_wino2.hip's fused F(2x2) form is not used (FACEHIP_WINO2=0: never)
+    static long v = -1;
+    if (v < 0) {
+        const char* e = getenv("FACEHIP_WINO2");
+        const char* m = getenv("FACEHIP_WINO2_MIN");
+        v = e && atoi(e) == 0 ? (1L << 60) : m ? atol(m) : 256;
+    }
+    return v;
+}
 
 Net::Net(const std::string& onnx_path, int default_h, int default_w) {
     OnnxModel m = load_onnx(onnx_path);
@@ -169,6 +178,19 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
                     conv_halo_pack_weights(op.weight.data(), op.Cout, op.Cin, wf.data());
                     d.wfrag = push(wf.data(), wf.size());
                     d.halo = true;
+                }
+            }
+            // fused Winograd F(2x2,3x3) image (conv_wino2.hip) for the 3x3 stride-1 convolutions below the F(4x4) threshold: the weights
+            // here already carry the block's folded BatchNorm (loop above), whose 9 bias classes the kernel's epilogue applies
+            if (op.kind == OpKind::CONV && op.Cin < kWinoMinCin && op.outs.empty()) {
+                ConvArgs probe{};
+                probe.ks = op.ks; probe.stride = op.stride; probe.pad = op.pad; probe.Cin = op.Cin; probe.Cout = op.Cout; probe.act = (int)op.act;
+                probe.res_mode = (int)op.res_mode; probe.H = op.H; probe.W = op.W; probe.Ho = op.Ho; probe.Wo = op.Wo;
+                if (wino2_ok(probe)) {
+                    std::vector<float> u(wino2_weight_floats(op.Cin, op.Cout));
+                    wino2_pack_weights(op.weight.data(), op.Cout, op.Cin, u.data());
+                    d.w2 = push(u.data(), u.size());
+                    d.w2ok = true;
                 }
             }
             // Winograd F(4x4,3x3) image of the same filter: U[f] = G g G^T in fp64, one packed [rows][Cin] matrix per frequency
@@ -441,6 +463,13 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 if (d.halo && halo_conv && force_cfg < 0) {
                     launch_conv_halo(a, P + d.wfrag, s);
                     tag = 9;
+                    break;
+                }
+                // fused F(2x2,3x3) for the few-channel 3x3 layers once there is at least one workgroup (2 tile groups of 4 x 7|8 tiles x 64
+                // channels) per CU; below that the direct kernel's split-K fills the chip better
+                if (d.w2ok && winograd && force_cfg < 0 && d.sc_src < 0 && wino2_blocks(a) >= wino2_min_blocks()) {
+                    a.wt = P + d.w2;
+                    launch_wino2(a, s);
                     break;
                 }
                 const bool use_wino = d.wino && winograd && (long)batch * ((op.H + 3) / 4) * ((op.W + 3) / 4) >= kWinoMinTiles;

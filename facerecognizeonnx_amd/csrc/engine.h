@@ -78,6 +78,8 @@ class Net {
         size_t wfrag = 0;                                     // halo-conv weights in MFMA fragment order (conv_halo.hip)
         bool halo = false;                                    // eligible for the spatial-tile 3x3 kernel
         bool wino = false;                                    // eligible: 3x3 stride 1 pad 1, Cin >= 128
+        size_t w2 = 0;                                        // fused Winograd F(2x2,3x3) image of the filter (conv_wino2.hip): 3x3 stride 1 pad 1,
+        bool w2ok = false;                                    //   32 <= Cin < 128, Cout % 64 == 0 (IResNet's 64-channel stages)
         int aff_src = -1;                                     // Winograd op whose input is op[aff_src]'s second (BatchNorm) output and its only
                                                               // consumer: the transform reads op[aff_src].out and applies that affine itself
         int aff_dst = -1;                                     // ... and the producer's side of the same link
