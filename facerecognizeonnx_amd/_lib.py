@@ -126,6 +126,7 @@ PROTOTYPES = {
     "fh_resize_u8c3_dev": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "fh_conv_forward_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fh_conv_winograd_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "fh_debug_wino2_stamps": (_vp, []),
     "fh_conv_wino2_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fh_conv_wt_rows": (_i, [_i]),
     "fh_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
@@ -139,6 +140,9 @@ def lib() -> C.CDLL:
     global _LIB
     if _LIB is None:
         path = build()
+        # FACEHIP_LIB: a diagnostic build of the same library (phase stamps: scripts/wino2_prof.sh) loaded INSTEAD of the in-tree one —
+        # a side copy, so that a failed diagnostic run can never leave a non-production library installed
+        path = os.environ.get("FACEHIP_LIB") or path
         # PyTorch (device memory / streams / torch.distributed plumbing) bundles its own HIP
         # runtime.  It has to be loaded FIRST so that libfacehip.so binds to the same runtime
         # instance; two runtimes in one process do not share a device context.

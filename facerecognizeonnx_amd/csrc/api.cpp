@@ -800,6 +800,7 @@ int fh_conv_wino2_dev(const float* d_in, const float* w_ohwi, const float* d_bia
         return 0;
     });
 }
+const void* fh_debug_wino2_stamps(void) { return fh::wino2_stamp_buffer(); }
 int fh_conv_wt_rows(int cout) { return fh::conv_wt_rows(cout); }
 int fh_conv_pack_weights(const float* w_ohwi, int cout, int cin, int ksize, float* dst_packed) {
     if (!w_ohwi || !dst_packed || cout <= 0 || cin <= 0) return arg_error("fh_conv_pack_weights: bad argument");

@@ -63,6 +63,8 @@ constexpr int kSA[4] = {1, 1, 1, 1}, kSB[4] = {-1, 1, -1, -1};
 // A^T = [ 1 1 1 0 ; 0 1 -1 -1 ]: coefficient of frequency row i in output row a
 constexpr int kAT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
 
+template <int V> struct IC { static constexpr int value = V; };          // compile-time integers for the fold over frequencies
+
 template <int TGC> struct Geo {
     static constexpr int PW = TGC + 1;                 // plane width (pixels of one column parity)
     static constexpr int PH = 5;                       // plane height: 4 tile rows + 1
@@ -91,7 +93,10 @@ template <int TGC> __device__ __forceinline__ void lane_tile(int t, int& tr, int
 }
 
 // One workgroup: tile groups 2*pair, 2*pair + 1 (linear over batch x group rows x group columns) x output channels [64 tile_n, +64).
-template <int TGC>
+// WREG: the weight fragments go global -> registers (each wave fetches the 4 KB of U_f it multiplies, one frequency ahead; the two waves of
+// a workgroup that share a channel half hit the same lines in L1) instead of through an LDS stage shared by the workgroup: no barrier
+// inside a 32-channel chunk, the waves of a workgroup run apart and overlap each other's LDS / VALU / MFMA phases.
+template <int TGC, bool WREG>
 __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const int tiles_n, const int tgx, const int tgy, const int n_tg) {
     using G = Geo<TGC>;
     constexpr int PW = G::PW, PH = G::PH, RPT = G::RPT, NP = G::NP;
@@ -102,6 +107,14 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tgi = wid >> 1, mb = wid & 1;                                // this wave's tile group / 32-channel half of the column tile
+#ifdef FACEHIP_W2_PROF
+    unsigned w2st[8] = {0, 0, 0, 0, 0, 0, 0, 0};                           // (32-bit, constant indices only: eight scalar registers)
+    const long long w2rt0 = __builtin_amdgcn_s_memrealtime();
+#define W2_STAMP(i) { w2st[i] = (unsigned)__builtin_readcyclecounter(); }
+#else
+#define W2_STAMP(i)
+#endif
+    W2_STAMP(0)
     int blk;
     {
         const int n = gridDim.x, q = n >> 3, r = n & 7, x = blockIdx.x & 7;
@@ -114,6 +127,17 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
 
     // ---- halo loader: pass i fills LDS rows i * 32 + (tid >> 3), physical column tid & 7
     unsigned a_off[NP];                                                    // element offset into p.in, ~0u = the zero line
+    // (image, group row, group column) of the workgroup's two tile groups: wave-uniform, the second is the first's successor — the two
+    // runtime divisions happen once per workgroup on scalars, not per lane and loader pass
+    int gn[2], ggy[2], ggx[2];
+    {
+        const int tg0 = 2 * pair;
+        const int n = tg0 / per_img, rem = tg0 - n * per_img;
+        const int gy = rem / tgx;
+        gn[0] = __builtin_amdgcn_readfirstlane(n); ggy[0] = __builtin_amdgcn_readfirstlane(gy); ggx[0] = __builtin_amdgcn_readfirstlane(rem - gy * tgx);
+        gn[1] = gn[0]; ggy[1] = ggy[0]; ggx[1] = ggx[0] + 1;
+        if (ggx[1] == tgx) { ggx[1] = 0; if (++ggy[1] == tgy) { ggy[1] = 0; ++gn[1]; } }
+    }
     {
         const int col = tid & 7;
 #pragma unroll
@@ -122,11 +146,9 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
             const int g = R / RPT, rr = R - g * RPT;
             const int pl = rr / (PH * PW), r2 = rr - pl * (PH * PW);
             const int pr = r2 / PW, pc = r2 - pr * PW;
-            const int tg = 2 * pair + g;
-            const int n = tg / per_img, rem = tg - n * per_img;
-            const int gy = rem / tgx, gx = rem - gy * tgx;
+            const int n = g ? gn[1] : gn[0], gy = g ? ggy[1] : ggy[0], gx = g ? ggx[1] : ggx[0];
             const int y = 8 * gy - 1 + 2 * pr + (pl >> 1), x = 2 * TGC * gx - 1 + 2 * pc + (pl & 1);
-            const bool ok = g < 2 && tg < n_tg && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const bool ok = g < 2 && 2 * pair + g < n_tg && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
             const int lc = col ^ row_key<TGC>(pl, pr, pc);
             a_off[i] = ok ? (unsigned)((((size_t)n * H + y) * W + x) * Cin + lc * 4) : ~0u;
         }
@@ -145,6 +167,8 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
     const int t = lane & 31, h = lane >> 5;
     int tr, tc; bool live;
     lane_tile<TGC>(t, tr, tc, live);
+    typedef const __attribute__((address_space(3))) v4f* lds_v4f;
+    const unsigned halo_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)halo;
     unsigned rb[16];
 #pragma unroll
     for (int dy = 0; dy < 4; ++dy)
@@ -152,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
         for (int dx = 0; dx < 4; ++dx) {
             const int pl = (dy & 1) * 2 + (dx & 1), pr = tr + (dy >> 1), pc = tc + (dx >> 1);
             const int R = tgi * RPT + (pl * PH + pr) * PW + pc;
-            rb[dy * 4 + dx] = (unsigned)(R * 128 + ((row_key<TGC>(pl, pr, pc) ^ h) << 4));
+            rb[dy * 4 + dx] = halo_base + (unsigned)(R * 128 + ((row_key<TGC>(pl, pr, pc) ^ h) << 4));   // (halo_base % 128 == 0: XOR-safe)
         }
     const char* const wfrag = wbuf + (mb * 4 * 64 + lane) * 16;            // + buffer * 8192 + g * 1024
 
@@ -178,80 +202,125 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
         epv[k] = v;
     }
 
-    // Y[a][b] += AT[a][i] * AT[b][j] * M   (frequency f = 4 i + j)
-    auto y_update = [&](const int f, const v16f& M) __attribute__((always_inline)) {
-        const int i = f >> 2, j = f & 3;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int cf = kAT[a][i] * kAT[b][j];
-                if (cf > 0) Y[a][b] += M;
-                else if (cf < 0) Y[a][b] -= M;
-            }
+    // Y[a][b] += AT[a][i] * AT[b][j] * M   (frequency f = 4 i + j; whole accumulators: updating them register by register behind each
+    // MFMA was tried — the compiler then keeps eight stages' M tuples alive and sums them late: 300 spilled registers, 3x slower)
+    auto y_update = [&](auto fc, const v16f& M) __attribute__((always_inline)) {
+        constexpr int f = decltype(fc)::value, i = f >> 2, j = f & 3;
+        constexpr int c00 = kAT[0][i] * kAT[0][j], c01 = kAT[0][i] * kAT[1][j], c10 = kAT[1][i] * kAT[0][j], c11 = kAT[1][i] * kAT[1][j];
+        if constexpr (c00 > 0) Y[0][0] += M; else if constexpr (c00 < 0) Y[0][0] -= M;
+        if constexpr (c01 > 0) Y[0][1] += M; else if constexpr (c01 < 0) Y[0][1] -= M;
+        if constexpr (c10 > 0) Y[1][0] += M; else if constexpr (c10 < 0) Y[1][0] -= M;
+        if constexpr (c11 > 0) Y[1][1] += M; else if constexpr (c11 < 0) Y[1][1] -= M;
     };
-
     const int NC = Cin >> 5, NS = NC * 16;
+#ifdef FACEHIP_W2_PROF
+    const bool abl_no_halo = p.sk_test_drop & 1;                          // ablations (FACEHIP_W2_ABLATE bits): 1 = skip the halo DMA (stale LDS),
+    const bool abl_no_store = p.sk_test_drop & 2;                         // 2 = skip the epilogue's loads and stores
+#else
+    constexpr bool abl_no_halo = false;
+#endif
     v16f Mprev;
 #pragma unroll
     for (int e = 0; e < 16; ++e) Mprev[e] = 0.f;
-    load_w(0, 0);
-    for (int c = 0; c < NC; ++c) {
+    // One frequency f (a compile-time constant: the loop over f is a fold over 16 instantiations — `#pragma unroll` gives up on a body
+    // of this size and a run-time f turns every B^T / A^T coefficient into a branch): 4 k-groups x 4 MFMAs, the patch pixels of the next
+    // step fetched one step ahead, the previous frequency's accumulator register m folded into the outputs right behind MFMA m.
+    v4f d[2][4];
+    auto fetch_d = [&](auto fc, auto gc, auto bc) __attribute__((always_inline)) {
+        constexpr int f = decltype(fc)::value, g = decltype(gc)::value, buf = decltype(bc)::value;
+        constexpr int fi = f >> 2, fj = f & 3;
+        constexpr int ya = kYA[fi], yb = kYB[fi], xa = kYA[fj], xb = kYB[fj];
+        // rb[] are absolute LDS addresses (no base add per read); the k-group's column bits come from a scalar the optimiser cannot see
+        // through — otherwise the 16 x 3 XORed addresses are computed once and kept in 48 registers for the whole loop; g = 0 needs none
+        unsigned gx = g << 5;
+        if constexpr (g > 0) asm volatile("" : "+s"(gx));
+        d[buf][0] = *reinterpret_cast<lds_v4f>((size_t)(rb[ya * 4 + xa] ^ gx));
+        d[buf][1] = *reinterpret_cast<lds_v4f>((size_t)(rb[ya * 4 + xb] ^ gx));
+        d[buf][2] = *reinterpret_cast<lds_v4f>((size_t)(rb[yb * 4 + xa] ^ gx));
+        d[buf][3] = *reinterpret_cast<lds_v4f>((size_t)(rb[yb * 4 + xb] ^ gx));
+    };
+    v4f wr[2][4];                                                          // weight fragments: [stage parity][k-group]
+    const float* const wg_src = p.wt + (size_t)tile_n * (Cin >> 5) * 16 * 2048 + (mb * 4 * 64 + lane) * 4;   // WREG: this wave's 4 KB of a stage
+    auto fetch_w = [&](int s, int buf) __attribute__((always_inline)) {   // WREG: global -> registers, 4 x (64 lanes x 16 B), k-group g at + g KB
+        const float* src = wg_src + (size_t)s * 2048;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wr[buf][g] = *reinterpret_cast<const v4f*>(src + g * 256);
+    };
+    int c = 0;
+    auto stage = [&](auto fc) __attribute__((always_inline)) {
+        constexpr int f = decltype(fc)::value;
+        constexpr int fi = f >> 2, fj = f & 3;
+        constexpr int saa = kSA[fi] * kSA[fj], sab = kSA[fi] * kSB[fj], sba = kSB[fi] * kSA[fj], sbb = kSB[fi] * kSB[fj];
+        // the next stage's weights (the very last stage re-fetches itself: no branch in the loop body)
+        if constexpr (WREG) fetch_w(min(c * 16 + f + 1, NS - 1), (f + 1) & 1);
+        else load_w(min(c * 16 + f + 1, NS - 1), (f + 1) & 1);
+        const char* const wf = wfrag + (f & 1) * 8192;                    // !WREG: this stage's fragments in the LDS stage
+        if constexpr (!WREG) wr[0][0] = *reinterpret_cast<const v4f*>(wf);
+        v16f M;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) M[e] = 0.f;
+        auto step = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value, k = f * 4 + g;
+            if constexpr (g < 3) fetch_d(IC<f>{}, IC<g + 1>{}, IC<(k + 1) & 1>{});
+            else if constexpr (f < 15) fetch_d(IC<f + 1>{}, IC<0>{}, IC<(k + 1) & 1>{});
+            if constexpr (!WREG && g < 3) wr[0][(g + 1) & 1] = *reinterpret_cast<const v4f*>(wf + (g + 1) * 1024);
+            __builtin_amdgcn_sched_barrier(0);                             // (reads issued BEFORE the MFMAs: left alone the scheduler sinks them)
+            const v4f* dd = d[k & 1];
+            v4f v = saa > 0 ? dd[0] : -dd[0];
+            v = sab > 0 ? v + dd[1] : v - dd[1];
+            v = sba > 0 ? v + dd[2] : v - dd[2];
+            v = sbb > 0 ? v + dd[3] : v - dd[3];
+            asm volatile("" : "+v"(v));                                    // (pins all of V in front of the MFMAs: otherwise each MFMA is preceded
+            __builtin_amdgcn_sched_barrier(0);                             //  by its three adds and a VALU -> MFMA-operand nop)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) M = __builtin_amdgcn_mfma_f32_32x32x2f32(WREG ? wr[f & 1][g][e] : wr[0][g & 1][e], v[e], M, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
+        y_update(IC<(f + 15) & 15>{}, Mprev);                              // the previous frequency's result -> the outputs, while this one's MFMAs run
+        Mprev = M;                                                         // (Mprev = 0 in front of the very first stage)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!WREG && f < 15) __syncthreads();                    // next weight stage landed; everyone is done with this one
+    };
+    if constexpr (WREG) fetch_w(0, 0);
+    else load_w(0, 0);
+    for (c = 0; c < NC; ++c) {
         if (c > 0) __syncthreads();                                        // every wave is done with the previous chunk's halo
 #pragma unroll
         for (int i = 0; i < NP; ++i)
-            dma16(a_off[i] != ~0u ? p.in + a_off[i] + c * 32 : p.zeros, halo + (i * 32 + wid * 8) * 128);
-        __syncthreads();                                                   // (drains vmcnt: halo chunk + this stage's weights have landed)
-#pragma unroll
-        for (int f = 0; f < 16; ++f) {
-            // next stage's weights into the other buffer (the very last stage re-fetches itself: no branch in the loop body)
-            load_w(min(c * 16 + f + 1, NS - 1), (f + 1) & 1);
-            const int fi = f >> 2, fj = f & 3;
-            const int ya = kYA[fi], yb = kYB[fi], xa = kYA[fj], xb = kYB[fj];
-            const int saa = kSA[fi] * kSA[fj], sab = kSA[fi] * kSB[fj], sba = kSB[fi] * kSA[fj], sbb = kSB[fi] * kSB[fj];
-            const char* const wf = wfrag + (f & 1) * 8192;
-            const unsigned r00 = rb[ya * 4 + xa], r01 = rb[ya * 4 + xb], r10 = rb[yb * 4 + xa], r11 = rb[yb * 4 + xb];
-            v16f M;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) M[e] = 0.f;
-            v4f d[2][4], w[2];
-            auto fetch = [&](int g) __attribute__((always_inline)) {
-                d[g & 1][0] = *reinterpret_cast<const v4f*>(halo + (r00 ^ (g << 5)));
-                d[g & 1][1] = *reinterpret_cast<const v4f*>(halo + (r01 ^ (g << 5)));
-                d[g & 1][2] = *reinterpret_cast<const v4f*>(halo + (r10 ^ (g << 5)));
-                d[g & 1][3] = *reinterpret_cast<const v4f*>(halo + (r11 ^ (g << 5)));
-                w[g & 1] = *reinterpret_cast<const v4f*>(wf + g * 1024);
-            };
-            fetch(0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (g < 3) fetch(g + 1);                                   // the next k-group's fragments are in flight behind this one's MFMAs
-                const v4f* dd = d[g & 1];
-                v4f v = saa > 0 ? dd[0] : -dd[0];
-                v = sab > 0 ? v + dd[1] : v - dd[1];
-                v = sba > 0 ? v + dd[2] : v - dd[2];
-                v = sbb > 0 ? v + dd[3] : v - dd[3];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) M = __builtin_amdgcn_mfma_f32_32x32x2f32(w[g & 1][e], v[e], M, 0, 0, 0);
-            }
-            // the previous frequency's result goes into the outputs while this one's MFMAs run (Mprev = 0 in front of the first stage)
-            y_update((f + 15) & 15, Mprev);
-            Mprev = M;
-            if (f < 15) __syncthreads();                                   // next weight stage landed; everyone is done with this one
-        }
+            if (!abl_no_halo) dma16(a_off[i] != ~0u ? p.in + a_off[i] + c * 32 : p.zeros, halo + (i * 32 + wid * 8) * 128);
+        __syncthreads();                                                   // (drains vmcnt: the halo chunk (+ the first weight stage) has landed)
+        fetch_d(IC<0>{}, IC<0>{}, IC<0>{});
+        stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{}); stage(IC<4>{}); stage(IC<5>{}); stage(IC<6>{}); stage(IC<7>{});
+        stage(IC<8>{}); stage(IC<9>{}); stage(IC<10>{}); stage(IC<11>{}); stage(IC<12>{}); stage(IC<13>{}); stage(IC<14>{}); stage(IC<15>{});
     }
-    y_update(15, Mprev);
+    y_update(IC<15>{}, Mprev);
     __syncthreads();                                                       // K loop over: the weight buffers are free
-    float* const ep = reinterpret_cast<float*>(wbuf);
+#ifdef FACEHIP_W2_PROF
+    auto w2_flush = [&]() {
+        W2_STAMP(7)
+        if (lane == 0 && p.slabs && blockIdx.x < 4096) {                   // [workgroup][wave][8]: stamps 1..7 relative to stamp 0; [7] = shader MHz x 10
+            long long* o = reinterpret_cast<long long*>(p.slabs) + ((size_t)blockIdx.x * 4 + wid) * 8;
+#pragma unroll
+            for (int i = 1; i < 8; ++i) o[i - 1] = (long long)(unsigned)(w2st[i] - w2st[0]);
+            o[7] = (long long)(unsigned)(w2st[7] - w2st[0]) * 1000 / ((long long)__builtin_amdgcn_s_memrealtime() - w2rt0 + 1);
+        }
+    };
+#endif
+    float* const ep = reinterpret_cast<float*>(WREG ? halo : wbuf);
 #pragma unroll
     for (int k = 0; k < 3; ++k) ep[tid + k * 256] = epv[k];
     __syncthreads();
 
     // ---- epilogue: lane = tile (tr, tc) of group 2 pair + tgi, accumulator quad q = channels n0 + 32 mb + 8 q + 4 h .. + 3
     const int tg = 2 * pair + tgi;
+#ifdef FACEHIP_W2_PROF
+    W2_STAMP(6)                                                            // K loop + barriers + epilogue vectors in LDS
+    if (!live || tg >= n_tg || abl_no_store) { w2_flush(); return; }
+#else
     if (!live || tg >= n_tg) return;
-    const int n = tg / per_img, rem = tg - n * per_img;
-    const int gy = rem / tgx, gx = rem - gy * tgx;
+#endif
+    const int n = gn[tgi], gy = ggy[tgi], gx = ggx[tgi];
     const int oy0 = 2 * (4 * gy + tr), ox0 = 2 * (TGC * gx + tc);
     const int cl0 = 32 * mb + 4 * h;                                       // channel within the column tile (quad 0)
     const float* __restrict__ res = p.res;
@@ -287,6 +356,9 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
                 }
             }
         }
+#ifdef FACEHIP_W2_PROF
+    w2_flush();
+#endif
 }
 
 int pick_tgc(int W) {
@@ -295,22 +367,28 @@ int pick_tgc(int W) {
     return g7 < g8 ? 7 : 8;
 }
 
-template <int TGC>
+int wreg_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FACEHIP_WINO2_WREG"); v = e ? atoi(e) : 1; }   // (0 = weights through the shared LDS stage: A / B timing)
+    return v;
+}
+
+template <int TGC, bool WREG>
 void launch_tgc(const ConvArgs& a, hipStream_t s) {
     const int ht = (a.H + 1) / 2, wt = (a.W + 1) / 2;
     const int tgy = (ht + 3) / 4, tgx = (wt + TGC - 1) / TGC;
     const long n_tg = (long)a.B * tgy * tgx;
     const int tiles_n = a.Cout / 64;
     const long blocks = (n_tg + 1) / 2 * tiles_n;
-    const size_t lds = Geo<TGC>::HALO_BYTES + 2 * 8192;
+    const size_t lds = Geo<TGC>::HALO_BYTES + (WREG ? 0 : 2 * 8192);
     static bool attr_done = false;
     if (!attr_done) {
-        FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino2_kernel<TGC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino2_kernel<TGC, WREG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
-    hipLaunchKernelGGL((wino2_kernel<TGC>), dim3((unsigned)blocks), dim3(256), lds, s, a, tiles_n, tgx, tgy, (int)n_tg);
+    hipLaunchKernelGGL((wino2_kernel<TGC, WREG>), dim3((unsigned)blocks), dim3(256), lds, s, a, tiles_n, tgx, tgy, (int)n_tg);
     // booked with the FLOPs the matrix cores EXECUTE (16 products per 2x2 tile and channel pair, idle lanes included)
     timer.end(s, 12, 2.0 * 16 * 32.0 * (double)((n_tg + 1) / 2 * 2) * a.Cin * a.Cout, a.t_flops);   // (bytes slot: the layer's direct-form FLOPs, as tag 7)
 }
@@ -347,6 +425,13 @@ bool wino2_ok(const ConvArgs& a) {
            (a.res_mode == (int)ResMode::NONE || a.res_mode == (int)ResMode::SAME);
 }
 
+// diagnostic builds (-DFACEHIP_W2_PROF, scripts/wino2_prof.sh): device buffer the kernel's phase stamps go to (1 MB, allocated on first use)
+static float* g_w2_stamps = nullptr;
+const void* wino2_stamp_buffer() {
+    if (!g_w2_stamps) { void* q = nullptr; if (hipMalloc(&q, 1 << 20) == hipSuccess) { (void)hipMemset(q, 0, 1 << 20); g_w2_stamps = (float*)q; } }
+    return g_w2_stamps;
+}
+
 long wino2_blocks(const ConvArgs& a) {
     const int tgc = pick_tgc(a.W);
     const long n_tg = (long)a.B * (((a.H + 1) / 2 + 3) / 4) * (((a.W + 1) / 2 + tgc - 1) / tgc);
@@ -358,8 +443,11 @@ void launch_wino2(const ConvArgs& a_in, hipStream_t s) {
     if (!wino2_ok(a_in)) throw std::runtime_error("launch_wino2: layer shape not supported");
     ConvArgs a = a_in;
     a.zeros = conv_zero_line();
-    if (pick_tgc(a.W) == 7) launch_tgc<7>(a, s);
-    else launch_tgc<8>(a, s);
+    a.slabs = g_w2_stamps;                                                 // (null unless a diagnostic run asked for the stamp buffer)
+    { const char* e = getenv("FACEHIP_W2_ABLATE"); a.sk_test_drop = e ? atoi(e) : 0; }   // (read by diagnostic builds only)
+    const bool wreg = wreg_mode() != 0;
+    if (pick_tgc(a.W) == 7) { if (wreg) launch_tgc<7, true>(a, s); else launch_tgc<7, false>(a, s); }
+    else { if (wreg) launch_tgc<8, true>(a, s); else launch_tgc<8, false>(a, s); }
 }
 
 }  // namespace fh

@@ -1,0 +1,14 @@
+#!/bin/bash
+# diagnostic build of conv_wino2.hip with phase stamps, installed as a SIDE copy of the library (FACEHIP_LIB), then scripts/wino2_prof.py
+set -e
+cd "$(dirname "$0")/.."
+B=build/facehip
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -DFACEHIP_W2_PROF -c facerecognizeonnx_amd/csrc/conv_wino2.hip -o $B/conv_wino2_prof.o
+OBJS=$(ls $B/*.o | grep -v "conv_wino2.o" | grep -v "_prof.o")
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o /tmp/libfacehip_w2prof.so $OBJS $B/conv_wino2_prof.o -lz
+for shape in "${@:-56 56 64 64}"; do
+  for wreg in 1 0; do for abl in 0 1 2 3; do
+    echo "== $shape  weights via registers=$wreg  ablation=$abl (1 = no halo DMA, 2 = no epilogue memory traffic)"
+    FACEHIP_WINO2_WREG=$wreg FACEHIP_W2_ABLATE=$abl FACEHIP_LIB=/tmp/libfacehip_w2prof.so python scripts/wino2_prof.py $shape 2>&1 | grep -v amdgpu.ids
+  done; done
+done
