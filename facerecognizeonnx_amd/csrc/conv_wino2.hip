@@ -26,6 +26,7 @@
 // direct fp32 form (tests/test_gpu_round4.py bars single layers at 5e-5 abs on O(1) outputs; winograd.hip's F(4x4) needs 2e-4).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -361,6 +362,246 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Persistent form (the default): 2 workgroups per CU walk the (tile-group pair, column tile) blocks of their XCD's contiguous range.
+// What the one-block-per-workgroup kernel above pays per block — ~12 k cycles of prologue (index arithmetic, the epilogue vectors' global
+// loads and their wait) and the first halo chunk's HBM latency, 15 % of a block (scripts/wino2_prof.sh) — is paid once per workgroup here:
+//   * per-lane loader constants (patch position, swizzled column), LDS read addresses and the epilogue vectors of ALL output channels
+//     (12 x Cout floats in LDS) are set up once;
+//   * a block's coordinates are two scalar divisions; its halo offsets are ~8 VALU per loader pass;
+//   * the NEXT block's first halo chunk and first weight fragments are requested before the epilogue of the current block: the DMA's
+//     latency hides behind the epilogue's LDS reads, arithmetic and store issue.
+// Weights always go global -> registers (WREG form above).
+template <int TGC>
+__global__ __launch_bounds__(256, 2) void wino2p_kernel(const ConvArgs p, const int tiles_n, const int tgx, const int tgy, const int n_tg,
+                                                        const int n_blocks) {
+    using G = Geo<TGC>;
+    constexpr int PW = G::PW, PH = G::PH, RPT = G::RPT, NP = G::NP;
+    extern __shared__ v4f w2sm[];
+    char* const halo = reinterpret_cast<char*>(w2sm);                      // [2 groups][RPT rows][8 x 16 B]
+    float* const ep = reinterpret_cast<float*>(halo + G::HALO_BYTES);      // [12][Cout]: 9 bias classes | slope | s2 | t2
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tgi = wid >> 1, mb = wid & 1;
+    const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
+    const int per_img = tgx * tgy;
+    // this workgroup's blocks: XCD x (= blockIdx % 8) owns a contiguous range of blocks, its workgroups take them round-robin
+    int blk, blk_end;
+    const int blk_step = (int)(gridDim.x >> 3);
+    {
+        const int q = n_blocks >> 3, r = n_blocks & 7, x = blockIdx.x & 7;
+        const int start = x * q + min(x, r);
+        blk = start + (int)(blockIdx.x >> 3);
+        blk_end = start + q + (x < r ? 1 : 0);
+    }
+    if (blk >= blk_end) return;
+
+    // ---- epilogue vectors of every output channel -> LDS (visible after the first barrier below)
+    for (int e = tid; e < 12 * Cout; e += 256) {
+        const int a = e / Cout, co = e - a * Cout;
+        float v = 0.f;
+        if (a < 9) { if (p.bias && (a == 0 || p.bias_cls)) v = p.bias[a * Cout + co]; }
+        else if (a == 9) v = p.act == (int)Act::PRELU ? p.slope[co] : 1.f;
+        else if (p.out2) v = a == 10 ? p.s2[co] : p.t2[co];
+        ep[e] = v;
+    }
+    // ---- loader constants: pass i fills LDS row i * 32 + (tid >> 3), physical column tid & 7 <- patch pixel (dy, dx) of group g, logical column lc
+    unsigned lcst[NP];                                                     // dy | dx << 4 | lc << 9 | g << 12 | valid << 13
+    {
+        const int col = tid & 7;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int R = i * 32 + (tid >> 3);
+            const int g = R / RPT, rr = R - g * RPT;
+            const int pl = rr / (PH * PW), r2 = rr - pl * (PH * PW);
+            const int pr = r2 / PW, pc = r2 - pr * PW;
+            const int dy = 2 * pr + (pl >> 1), dx = 2 * pc + (pl & 1), lc = col ^ row_key<TGC>(pl, pr, pc);
+            lcst[i] = g < 2 ? (unsigned)(dy | dx << 4 | lc << 9 | g << 12 | 1 << 13) : 0u;
+        }
+    }
+    const int t = lane & 31, h = lane >> 5;
+    int tr, tc; bool live;
+    lane_tile<TGC>(t, tr, tc, live);
+    typedef const __attribute__((address_space(3))) v4f* lds_v4f;
+    const unsigned halo_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)halo;
+    unsigned rb[16];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 4; ++dx) {
+            const int pl = (dy & 1) * 2 + (dx & 1), pr = tr + (dy >> 1), pc = tc + (dx >> 1);
+            const int R = tgi * RPT + (pl * PH + pr) * PW + pc;
+            rb[dy * 4 + dx] = halo_base + (unsigned)(R * 128 + ((row_key<TGC>(pl, pr, pc) ^ h) << 4));
+        }
+
+    // ---- per block: coordinates of its two tile groups (scalars) and the halo source offsets of this lane's loader passes
+    int gn[2], ggy[2], ggx[2], pair = 0, tile_n = 0;
+    unsigned a_off[NP];
+    auto locate = [&](int b) __attribute__((always_inline)) {
+        tile_n = b % tiles_n; pair = b / tiles_n;
+        const int tg0 = 2 * pair;
+        const int n = tg0 / per_img, rem = tg0 - n * per_img;
+        const int gy = rem / tgx;
+        gn[0] = __builtin_amdgcn_readfirstlane(n); ggy[0] = __builtin_amdgcn_readfirstlane(gy); ggx[0] = __builtin_amdgcn_readfirstlane(rem - gy * tgx);
+        gn[1] = gn[0]; ggy[1] = ggy[0]; ggx[1] = ggx[0] + 1;
+        if (ggx[1] == tgx) { ggx[1] = 0; if (++ggy[1] == tgy) { ggy[1] = 0; ++gn[1]; } }
+        const bool has1 = tg0 + 1 < n_tg;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const unsigned cst = lcst[i];
+            const int g = (cst >> 12) & 1;
+            const int y = 8 * (g ? ggy[1] : ggy[0]) - 1 + (int)(cst & 15), x = 2 * TGC * (g ? ggx[1] : ggx[0]) - 1 + (int)((cst >> 4) & 31);
+            const bool ok = (cst >> 13) && (g == 0 || has1) && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            a_off[i] = ok ? (unsigned)((((size_t)(g ? gn[1] : gn[0]) * H + y) * W + x) * Cin + ((cst >> 9) & 7) * 4) : ~0u;
+        }
+    };
+    auto load_halo = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) dma16(a_off[i] != ~0u ? p.in + a_off[i] + c * 32 : p.zeros, halo + (i * 32 + wid * 8) * 128);
+    };
+
+    v16f Y[2][2];
+    auto y_update = [&](auto fc, const v16f& M) __attribute__((always_inline)) {
+        constexpr int f = decltype(fc)::value, i = f >> 2, j = f & 3;
+        constexpr int c00 = kAT[0][i] * kAT[0][j], c01 = kAT[0][i] * kAT[1][j], c10 = kAT[1][i] * kAT[0][j], c11 = kAT[1][i] * kAT[1][j];
+        if constexpr (c00 > 0) Y[0][0] += M; else if constexpr (c00 < 0) Y[0][0] -= M;
+        if constexpr (c01 > 0) Y[0][1] += M; else if constexpr (c01 < 0) Y[0][1] -= M;
+        if constexpr (c10 > 0) Y[1][0] += M; else if constexpr (c10 < 0) Y[1][0] -= M;
+        if constexpr (c11 > 0) Y[1][1] += M; else if constexpr (c11 < 0) Y[1][1] -= M;
+    };
+    const int NC = Cin >> 5, NS = NC * 16;
+    v16f Mprev;
+    v4f d[2][4];
+    auto fetch_d = [&](auto fc, auto gc, auto bc) __attribute__((always_inline)) {
+        constexpr int f = decltype(fc)::value, g = decltype(gc)::value, buf = decltype(bc)::value;
+        constexpr int fi = f >> 2, fj = f & 3;
+        constexpr int ya = kYA[fi], yb = kYB[fi], xa = kYA[fj], xb = kYB[fj];
+        unsigned gx = g << 5;                                              // (opaque scalar: see wino2_kernel)
+        if constexpr (g > 0) asm volatile("" : "+s"(gx));
+        d[buf][0] = *reinterpret_cast<lds_v4f>((size_t)(rb[ya * 4 + xa] ^ gx));
+        d[buf][1] = *reinterpret_cast<lds_v4f>((size_t)(rb[ya * 4 + xb] ^ gx));
+        d[buf][2] = *reinterpret_cast<lds_v4f>((size_t)(rb[yb * 4 + xa] ^ gx));
+        d[buf][3] = *reinterpret_cast<lds_v4f>((size_t)(rb[yb * 4 + xb] ^ gx));
+    };
+    v4f wr[2][4];
+    const float* wg_src = nullptr;                                         // this wave's 4 KB of stage 0 of the current column tile
+    auto fetch_w = [&](int s, int buf) __attribute__((always_inline)) {
+        const float* src = wg_src + (size_t)s * 2048;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wr[buf][g] = *reinterpret_cast<const v4f*>(src + g * 256);
+    };
+    int c = 0;
+    auto stage = [&](auto fc) __attribute__((always_inline)) {
+        constexpr int f = decltype(fc)::value;
+        constexpr int fi = f >> 2, fj = f & 3;
+        constexpr int saa = kSA[fi] * kSA[fj], sab = kSA[fi] * kSB[fj], sba = kSB[fi] * kSA[fj], sbb = kSB[fi] * kSB[fj];
+        fetch_w(min(c * 16 + f + 1, NS - 1), (f + 1) & 1);                 // (the very last stage re-fetches itself: no branch in the loop body)
+        v16f M;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) M[e] = 0.f;
+        auto step = [&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value, k = f * 4 + g;
+            if constexpr (g < 3) fetch_d(IC<f>{}, IC<g + 1>{}, IC<(k + 1) & 1>{});
+            else if constexpr (f < 15) fetch_d(IC<f + 1>{}, IC<0>{}, IC<(k + 1) & 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            const v4f* dd = d[k & 1];
+            v4f v = saa > 0 ? dd[0] : -dd[0];
+            v = sab > 0 ? v + dd[1] : v - dd[1];
+            v = sba > 0 ? v + dd[2] : v - dd[2];
+            v = sbb > 0 ? v + dd[3] : v - dd[3];
+            asm volatile("" : "+v"(v));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) M = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[f & 1][g][e], v[e], M, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
+        y_update(IC<(f + 15) & 15>{}, Mprev);
+        Mprev = M;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    locate(blk);
+    wg_src = p.wt + (size_t)tile_n * (Cin >> 5) * 16 * 2048 + (mb * 4 * 64 + lane) * 4;
+    load_halo(0);
+    fetch_w(0, 0);
+    __syncthreads();                                                       // first halo chunk landed; epilogue vectors visible
+    const bool relu = p.act == (int)Act::RELU;
+    const int cl0 = 32 * mb + 4 * h;                                       // channel within the column tile (accumulator quad 0)
+    for (;;) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) Y[a][b][e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Mprev[e] = 0.f;
+        for (c = 0; c < NC; ++c) {
+            if (c > 0) {
+                __syncthreads();                                           // every wave is done with the previous chunk's halo
+                load_halo(c);
+                __syncthreads();                                           // (drains vmcnt: the chunk has landed)
+            }
+            fetch_d(IC<0>{}, IC<0>{}, IC<0>{});
+            stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{}); stage(IC<4>{}); stage(IC<5>{}); stage(IC<6>{}); stage(IC<7>{});
+            stage(IC<8>{}); stage(IC<9>{}); stage(IC<10>{}); stage(IC<11>{}); stage(IC<12>{}); stage(IC<13>{}); stage(IC<14>{}); stage(IC<15>{});
+        }
+        y_update(IC<15>{}, Mprev);
+        __syncthreads();                                                   // every wave is done reading this block's halo
+        // this block's epilogue coordinates, then the NEXT block's halo + first weights go out in front of the epilogue
+        const int e_n = gn[tgi], e_gy = ggy[tgi], e_gx = ggx[tgi], e_n0 = tile_n * 64;
+        const bool e_live = live && 2 * pair + tgi < n_tg;
+        const int nxt = blk + blk_step;
+        const bool more = nxt < blk_end;
+        if (more) {
+            locate(nxt);
+            wg_src = p.wt + (size_t)tile_n * (Cin >> 5) * 16 * 2048 + (mb * 4 * 64 + lane) * 4;
+            load_halo(0);
+            fetch_w(0, 0);
+        }
+        if (e_live) {
+            const int oy0 = 2 * (4 * e_gy + tr), ox0 = 2 * (TGC * e_gx + tc);
+            const float* __restrict__ res = p.res;
+            float* __restrict__ out1 = p.out1;
+            float* __restrict__ out2 = p.out2;
+            const float* const epc = ep + e_n0 + cl0;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int oy = oy0 + a, ox = ox0 + b;
+                    if (oy >= p.Ho || ox >= p.Wo) continue;
+                    const size_t row = (((size_t)e_n * p.Ho + oy) * p.Wo + ox) * Cout + e_n0 + cl0;
+                    const int cls = p.bias_cls ? 3 * (oy == 0 ? 0 : oy == p.Ho - 1 ? 2 : 1) + (ox == 0 ? 0 : ox == p.Wo - 1 ? 2 : 1) : 0;
+                    v4f r4[4];
+                    if (p.res_mode != (int)ResMode::NONE) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) r4[q] = *reinterpret_cast<const v4f*>(res + row + 8 * q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v4f b4 = *reinterpret_cast<const v4f*>(epc + cls * Cout + 8 * q);
+                        const v4f sl = *reinterpret_cast<const v4f*>(epc + 9 * Cout + 8 * q);
+                        v4f v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = act1(Y[a][b][4 * q + e] + b4[e], relu, sl[e]);
+                        if (p.res_mode != (int)ResMode::NONE) v += r4[q];
+                        if (out1) *reinterpret_cast<v4f*>(out1 + row + 8 * q) = v;
+                        if (out2) {
+                            const v4f s2 = *reinterpret_cast<const v4f*>(epc + 10 * Cout + 8 * q), t2 = *reinterpret_cast<const v4f*>(epc + 11 * Cout + 8 * q);
+                            *reinterpret_cast<v4f*>(out2 + row + 8 * q) = v * s2 + t2;
+                        }
+                    }
+                }
+        }
+        if (!more) break;
+        blk = nxt;
+        __syncthreads();                                                   // the next block's first halo chunk has landed
+    }
+}
+
 int pick_tgc(int W) {
     const int wt = (W + 1) / 2;                                            // tile columns of the map
     const int g7 = (wt + 6) / 7 * 8, g8 = (wt + 7) / 8 * 8;                // MFMA columns spent per tile row (a 7-wide group idles its eighth lane)
@@ -371,6 +612,33 @@ int wreg_mode() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("FACEHIP_WINO2_WREG"); v = e ? atoi(e) : 1; }   // (0 = weights through the shared LDS stage: A / B timing)
     return v;
+}
+
+int persist_mode() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FACEHIP_WINO2_PERSIST"); v = e ? atoi(e) : 1; }   // (0 = one block per workgroup: A / B timing, phase stamps)
+    return v;
+}
+
+template <int TGC>
+void launch_persistent(const ConvArgs& a, hipStream_t s) {
+    const int ht = (a.H + 1) / 2, wt = (a.W + 1) / 2;
+    const int tgy = (ht + 3) / 4, tgx = (wt + TGC - 1) / TGC;
+    const long n_tg = (long)a.B * tgy * tgx;
+    const int tiles_n = a.Cout / 64;
+    const long blocks = (n_tg + 1) / 2 * tiles_n;
+    const size_t lds = Geo<TGC>::HALO_BYTES + (size_t)12 * a.Cout * sizeof(float);
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino2p_kernel<TGC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const int cus = a.cus > 0 ? a.cus : conv_num_cus();
+    const long grid = std::min<long>((blocks + 7) / 8 * 8, 2L * cus);          // two workgroups per CU, a multiple of the 8 XCDs
+    KernelTimer& timer = KernelTimer::get();
+    timer.begin(s);
+    hipLaunchKernelGGL((wino2p_kernel<TGC>), dim3((unsigned)grid), dim3(256), lds, s, a, tiles_n, tgx, tgy, (int)n_tg, (int)blocks);
+    timer.end(s, 12, 2.0 * 16 * 32.0 * (double)((n_tg + 1) / 2 * 2) * a.Cin * a.Cout, a.t_flops);   // (bytes slot: the layer's direct-form FLOPs, as tag 7)
 }
 
 template <int TGC, bool WREG>
@@ -445,6 +713,10 @@ void launch_wino2(const ConvArgs& a_in, hipStream_t s) {
     a.zeros = conv_zero_line();
     a.slabs = g_w2_stamps;                                                 // (null unless a diagnostic run asked for the stamp buffer)
     { const char* e = getenv("FACEHIP_W2_ABLATE"); a.sk_test_drop = e ? atoi(e) : 0; }   // (read by diagnostic builds only)
+    if (persist_mode() && a.Cout <= 512) {
+        if (pick_tgc(a.W) == 7) launch_persistent<7>(a, s); else launch_persistent<8>(a, s);
+        return;
+    }
     const bool wreg = wreg_mode() != 0;
     if (pick_tgc(a.W) == 7) { if (wreg) launch_tgc<7, true>(a, s); else launch_tgc<7, false>(a, s); }
     else { if (wreg) launch_tgc<8, true>(a, s); else launch_tgc<8, false>(a, s); }
