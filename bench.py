@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--crops", type=int, default=256, help="--workload embed: pre-aligned crops per batch (config 2)")
     ap.add_argument("--score-thr", type=float, default=0.5)
     ap.add_argument("--nms-thr", type=float, default=0.4)
+    ap.add_argument("--stream-priority", default="rec", choices=["rec", "det", "none"],
+                    help="streaming e2e form: which of the two HIP streams gets the higher priority (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
@@ -456,7 +458,8 @@ def main():
             # runs beside the recogniser of batch k (HBM-bound next to MFMA-bound work); no host sync per batch.
             # A ring of 3 per-batch result buffers with event back-pressure keeps at most 3 batches in flight.
             RING = 3
-            s_det, s_rec = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+            pr = {"rec": (0, -1), "det": (-1, 0), "none": (0, 0)}[args.stream_priority]
+            s_det, s_rec = torch.cuda.Stream(priority=pr[0]), torch.cuda.Stream(priority=pr[1])
             rf = [torch.zeros((B * F, 15), device="cuda") for _ in range(RING)]
             ro = [torch.zeros(B * F, dtype=torch.int32, device="cuda") for _ in range(RING)]
             re_ = [torch.zeros((B * F, 512), device="cuda") for _ in range(RING)]

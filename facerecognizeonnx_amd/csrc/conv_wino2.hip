@@ -16,7 +16,7 @@
 //     is XOR-swizzled per row, conflict-free (scripts/wino2_banks.py enumerates every access of both configurations);
 //   * for each of the 16 frequencies f = (i, j) in turn: the lane forms V_f = (B^T d B)[i][j] of ITS tile for 4 channels from four
 //     ds_read_b128 and three packed adds (B^T has two +-1 entries per row) — a float4 that is exactly the B fragment the MFMA wants
-//     from that lane; U_f (64 x 32 per chunk, 8 KB, pre-arranged in fragment order) streams through a double-buffered LDS stage;
+//     from that lane; U_f (pre-arranged in fragment order) goes global -> registers, one frequency ahead (no barrier inside a chunk);
 //     16 MFMAs accumulate M_f, and M_f is added into the four output accumulators Y[a][b] with A^T's {0, +-1} coefficients
 //     (1, 2 or 4 adds per register) while the NEXT frequency's MFMAs run;
 //   * epilogue on the 2x2 pixels of the lane's tile: bias (9 border classes when the block's BatchNorm is folded in, engine.cpp) ->
@@ -94,16 +94,15 @@ template <int TGC> __device__ __forceinline__ void lane_tile(int t, int& tr, int
 }
 
 // One workgroup: tile groups 2*pair, 2*pair + 1 (linear over batch x group rows x group columns) x output channels [64 tile_n, +64).
-// WREG: the weight fragments go global -> registers (each wave fetches the 4 KB of U_f it multiplies, one frequency ahead; the two waves of
-// a workgroup that share a channel half hit the same lines in L1) instead of through an LDS stage shared by the workgroup: no barrier
-// inside a 32-channel chunk, the waves of a workgroup run apart and overlap each other's LDS / VALU / MFMA phases.
-template <int TGC, bool WREG>
+// The weight fragments go global -> registers (each wave fetches the 4 KB of U_f it multiplies, one frequency ahead; the two waves of a
+// workgroup that share a channel half hit the same lines in L1), not through an LDS stage shared by the workgroup (measured: 204 vs 197 us
+// on 56x56x64 at B = 128): no barrier inside a 32-channel chunk, the waves of a workgroup run apart and overlap each other's phases.
+template <int TGC>
 __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const int tiles_n, const int tgx, const int tgy, const int n_tg) {
     using G = Geo<TGC>;
     constexpr int PW = G::PW, PH = G::PH, RPT = G::RPT, NP = G::NP;
     extern __shared__ v4f w2sm[];
     char* const halo = reinterpret_cast<char*>(w2sm);                      // [2 groups][RPT rows][8 x 16 B]
-    char* const wbuf = halo + G::HALO_BYTES;                               // [2 buffers][8 KB]: U_f of one 32-channel chunk, fragment order
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -154,16 +153,6 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
             a_off[i] = ok ? (unsigned)((((size_t)n * H + y) * W + x) * Cin + lc * 4) : ~0u;
         }
     }
-    // ---- weight stage loader: stage s = chunk * 16 + f is 8 KB = 8 wave pieces of 1 KB; wave w moves pieces 2w, 2w + 1
-    const float* w_src = p.wt + (size_t)tile_n * (Cin >> 5) * 16 * 2048 + (wid * 2) * 256 + lane * 4;
-    char* const w_dst = wbuf + wid * 2048;
-    auto load_w = [&](int s, int buf) __attribute__((always_inline)) {
-        const float* src = w_src + (size_t)s * 2048;
-        char* dst = w_dst + buf * 8192;
-        dma16(src, dst);
-        dma16(src + 256, dst + 1024);
-    };
-
     // ---- this lane's tile and the LDS byte offsets of its 16 patch pixels (column bits: key ^ half; the k-group g adds ^ 32 g)
     const int t = lane & 31, h = lane >> 5;
     int tr, tc; bool live;
@@ -179,7 +168,6 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
             const int R = tgi * RPT + (pl * PH + pr) * PW + pc;
             rb[dy * 4 + dx] = halo_base + (unsigned)(R * 128 + ((row_key<TGC>(pl, pr, pc) ^ h) << 4));   // (halo_base % 128 == 0: XOR-safe)
         }
-    const char* const wfrag = wbuf + (mb * 4 * 64 + lane) * 16;            // + buffer * 8192 + g * 1024
 
     v16f Y[2][2];
 #pragma unroll
@@ -212,6 +200,11 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
         if constexpr (c01 > 0) Y[0][1] += M; else if constexpr (c01 < 0) Y[0][1] -= M;
         if constexpr (c10 > 0) Y[1][0] += M; else if constexpr (c10 < 0) Y[1][0] -= M;
         if constexpr (c11 > 0) Y[1][1] += M; else if constexpr (c11 < 0) Y[1][1] -= M;
+        // (pinned: a deferred update keeps its frequency's 16 accumulator registers alive — see wino2x_kernel)
+        if constexpr (c00 != 0) asm volatile("" : "+v"(Y[0][0]));
+        if constexpr (c01 != 0) asm volatile("" : "+v"(Y[0][1]));
+        if constexpr (c10 != 0) asm volatile("" : "+v"(Y[1][0]));
+        if constexpr (c11 != 0) asm volatile("" : "+v"(Y[1][1]));
     };
     const int NC = Cin >> 5, NS = NC * 16;
 #ifdef FACEHIP_W2_PROF
@@ -232,17 +225,17 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
         constexpr int fi = f >> 2, fj = f & 3;
         constexpr int ya = kYA[fi], yb = kYB[fi], xa = kYA[fj], xb = kYB[fj];
         // rb[] are absolute LDS addresses (no base add per read); the k-group's column bits come from a scalar the optimiser cannot see
-        // through — otherwise the 16 x 3 XORed addresses are computed once and kept in 48 registers for the whole loop; g = 0 needs none
+        // through — otherwise the 16 x 3 XORed addresses are computed once and kept in 48 registers for the whole loop
         unsigned gx = g << 5;
-        if constexpr (g > 0) asm volatile("" : "+s"(gx));
+        asm volatile("" : "+s"(gx));                                       // (for g = 0 too: reads that depend on nothing are hoisted stages ahead)
         d[buf][0] = *reinterpret_cast<lds_v4f>((size_t)(rb[ya * 4 + xa] ^ gx));
         d[buf][1] = *reinterpret_cast<lds_v4f>((size_t)(rb[ya * 4 + xb] ^ gx));
         d[buf][2] = *reinterpret_cast<lds_v4f>((size_t)(rb[yb * 4 + xa] ^ gx));
         d[buf][3] = *reinterpret_cast<lds_v4f>((size_t)(rb[yb * 4 + xb] ^ gx));
     };
     v4f wr[2][4];                                                          // weight fragments: [stage parity][k-group]
-    const float* const wg_src = p.wt + (size_t)tile_n * (Cin >> 5) * 16 * 2048 + (mb * 4 * 64 + lane) * 4;   // WREG: this wave's 4 KB of a stage
-    auto fetch_w = [&](int s, int buf) __attribute__((always_inline)) {   // WREG: global -> registers, 4 x (64 lanes x 16 B), k-group g at + g KB
+    const float* const wg_src = p.wt + (size_t)tile_n * (Cin >> 5) * 16 * 2048 + (mb * 4 * 64 + lane) * 4;   // this wave's 4 KB of stage 0
+    auto fetch_w = [&](int s, int buf) __attribute__((always_inline)) {   // global -> registers, 4 x (64 lanes x 16 B), k-group g at + g KB
         const float* src = wg_src + (size_t)s * 2048;
 #pragma unroll
         for (int g = 0; g < 4; ++g) wr[buf][g] = *reinterpret_cast<const v4f*>(src + g * 256);
@@ -253,10 +246,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
         constexpr int fi = f >> 2, fj = f & 3;
         constexpr int saa = kSA[fi] * kSA[fj], sab = kSA[fi] * kSB[fj], sba = kSB[fi] * kSA[fj], sbb = kSB[fi] * kSB[fj];
         // the next stage's weights (the very last stage re-fetches itself: no branch in the loop body)
-        if constexpr (WREG) fetch_w(min(c * 16 + f + 1, NS - 1), (f + 1) & 1);
-        else load_w(min(c * 16 + f + 1, NS - 1), (f + 1) & 1);
-        const char* const wf = wfrag + (f & 1) * 8192;                    // !WREG: this stage's fragments in the LDS stage
-        if constexpr (!WREG) wr[0][0] = *reinterpret_cast<const v4f*>(wf);
+        fetch_w(min(c * 16 + f + 1, NS - 1), (f + 1) & 1);
         v16f M;
 #pragma unroll
         for (int e = 0; e < 16; ++e) M[e] = 0.f;
@@ -264,7 +254,6 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
             constexpr int g = decltype(gc)::value, k = f * 4 + g;
             if constexpr (g < 3) fetch_d(IC<f>{}, IC<g + 1>{}, IC<(k + 1) & 1>{});
             else if constexpr (f < 15) fetch_d(IC<f + 1>{}, IC<0>{}, IC<(k + 1) & 1>{});
-            if constexpr (!WREG && g < 3) wr[0][(g + 1) & 1] = *reinterpret_cast<const v4f*>(wf + (g + 1) * 1024);
             __builtin_amdgcn_sched_barrier(0);                             // (reads issued BEFORE the MFMAs: left alone the scheduler sinks them)
             const v4f* dd = d[k & 1];
             v4f v = saa > 0 ? dd[0] : -dd[0];
@@ -274,29 +263,27 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
             asm volatile("" : "+v"(v));                                    // (pins all of V in front of the MFMAs: otherwise each MFMA is preceded
             __builtin_amdgcn_sched_barrier(0);                             //  by its three adds and a VALU -> MFMA-operand nop)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) M = __builtin_amdgcn_mfma_f32_32x32x2f32(WREG ? wr[f & 1][g][e] : wr[0][g & 1][e], v[e], M, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) M = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[f & 1][g][e], v[e], M, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
         step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
         y_update(IC<(f + 15) & 15>{}, Mprev);                              // the previous frequency's result -> the outputs, while this one's MFMAs run
         Mprev = M;                                                         // (Mprev = 0 in front of the very first stage)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!WREG && f < 15) __syncthreads();                    // next weight stage landed; everyone is done with this one
     };
-    if constexpr (WREG) fetch_w(0, 0);
-    else load_w(0, 0);
+    fetch_w(0, 0);
     for (c = 0; c < NC; ++c) {
         if (c > 0) __syncthreads();                                        // every wave is done with the previous chunk's halo
 #pragma unroll
         for (int i = 0; i < NP; ++i)
             if (!abl_no_halo) dma16(a_off[i] != ~0u ? p.in + a_off[i] + c * 32 : p.zeros, halo + (i * 32 + wid * 8) * 128);
-        __syncthreads();                                                   // (drains vmcnt: the halo chunk (+ the first weight stage) has landed)
+        __syncthreads();                                                   // (drains vmcnt: the halo chunk has landed)
         fetch_d(IC<0>{}, IC<0>{}, IC<0>{});
         stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{}); stage(IC<4>{}); stage(IC<5>{}); stage(IC<6>{}); stage(IC<7>{});
         stage(IC<8>{}); stage(IC<9>{}); stage(IC<10>{}); stage(IC<11>{}); stage(IC<12>{}); stage(IC<13>{}); stage(IC<14>{}); stage(IC<15>{});
     }
     y_update(IC<15>{}, Mprev);
-    __syncthreads();                                                       // K loop over: the weight buffers are free
+    __syncthreads();                                                       // K loop over: the halo image is free
 #ifdef FACEHIP_W2_PROF
     auto w2_flush = [&]() {
         W2_STAMP(7)
@@ -308,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
         }
     };
 #endif
-    float* const ep = reinterpret_cast<float*>(WREG ? halo : wbuf);
+    float* const ep = reinterpret_cast<float*>(halo);
 #pragma unroll
     for (int k = 0; k < 3; ++k) ep[tid + k * 256] = epv[k];
     __syncthreads();
@@ -363,66 +350,49 @@ __global__ __launch_bounds__(256, 2) void wino2_kernel(const ConvArgs p, const i
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Persistent form (the default): 2 workgroups per CU walk the (tile-group pair, column tile) blocks of their XCD's contiguous range.
-// What the one-block-per-workgroup kernel above pays per block — ~12 k cycles of prologue (index arithmetic, the epilogue vectors' global
-// loads and their wait) and the first halo chunk's HBM latency, 15 % of a block (scripts/wino2_prof.sh) — is paid once per workgroup here:
-//   * per-lane loader constants (patch position, swizzled column), LDS read addresses and the epilogue vectors of ALL output channels
-//     (12 x Cout floats in LDS) are set up once;
-//   * a block's coordinates are two scalar divisions; its halo offsets are ~8 VALU per loader pass;
-//   * the NEXT block's first halo chunk and first weight fragments are requested before the epilogue of the current block: the DMA's
-//     latency hides behind the epilogue's LDS reads, arithmetic and store issue.
-// Weights always go global -> registers (WREG form above).
-template <int TGC>
-__global__ __launch_bounds__(256, 2) void wino2p_kernel(const ConvArgs p, const int tiles_n, const int tgx, const int tgy, const int n_tg,
-                                                        const int n_blocks) {
-    using G = Geo<TGC>;
-    constexpr int PW = G::PW, PH = G::PH, RPT = G::RPT, NP = G::NP;
+// wino2x_kernel — the same algorithm on v_mfma_f32_16x16x4_f32 for layers with exactly 64 input channels: ONE WAVE per workgroup owns a
+// 4 x 4 tile group (8 x 8 outputs = the 16 MFMA columns) and ALL 16 CB output channels of its column tile.
+//   * 16 tiles per wave tile every map whose side is a multiple of 8 exactly (56 = 7 x 8: the 32-column form idles an eighth of its lanes
+//     there) and let one wave cover 64 channels, so V_f is formed ONCE per tile (the 32-column form computes it in both channel halves):
+//     per 1024 cycles of matrix-pipe time 24 + 18 VALU for V and the output update instead of 48 + 36, 8 ds_read_b128 instead of 16;
+//   * the whole 64-channel halo of the group (10 x 10 pixels x 256 B = 25.6 KB, four parity planes of 5 x 5 pixels, 16-byte column
+//     XOR-swizzled by 2 ((pc + 4 (pr & 1)) & 7): conflict-free, scripts/wino2_banks.py) is loaded once: no chunk switch, and — a wave
+//     only reads what it loaded itself — NO barrier anywhere in the kernel; six independent waves per CU (LDS-bound);
+//   * lane (tile n = lane & 15, kq = lane >> 4) holds channels 16 j + 4 kq + e of k-step group j: one float4 of V feeds 4 (e) x CB MFMAs;
+//     weights [f][j][cb][lane][4] go global -> registers one step ahead (4 KB per step; twice the L2 traffic per output of the
+//     32-column form: the price of 16 columns per wave).
+template <int CB>
+__global__ __launch_bounds__(64, 2) void wino2x_kernel(const ConvArgs p, const int tiles_n, const int tgx, const int tgy, const int n_tg) {
     extern __shared__ v4f w2sm[];
-    char* const halo = reinterpret_cast<char*>(w2sm);                      // [2 groups][RPT rows][8 x 16 B]
-    float* const ep = reinterpret_cast<float*>(halo + G::HALO_BYTES);      // [12][Cout]: 9 bias classes | slope | s2 | t2
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tgi = wid >> 1, mb = wid & 1;
-    const int H = p.H, W = p.W, Cin = p.Cin, Cout = p.Cout;
+    char* const halo = reinterpret_cast<char*>(w2sm);                      // [4 planes][5][5] pixels x 16 x 16 B
+    const int lane = threadIdx.x;
+    int blk;
+    {
+        const int n = gridDim.x, q = n >> 3, r = n & 7, x = blockIdx.x & 7;
+        blk = x * q + min(x, r) + (int)(blockIdx.x >> 3);                  // XCD-contiguous order
+    }
+    const int tile_n = blk % tiles_n, tg = blk / tiles_n;
+    const int H = p.H, W = p.W;
     const int per_img = tgx * tgy;
-    // this workgroup's blocks: XCD x (= blockIdx % 8) owns a contiguous range of blocks, its workgroups take them round-robin
-    int blk, blk_end;
-    const int blk_step = (int)(gridDim.x >> 3);
-    {
-        const int q = n_blocks >> 3, r = n_blocks & 7, x = blockIdx.x & 7;
-        const int start = x * q + min(x, r);
-        blk = start + (int)(blockIdx.x >> 3);
-        blk_end = start + q + (x < r ? 1 : 0);
-    }
-    if (blk >= blk_end) return;
+    const int gn = tg / per_img, rem = tg - gn * per_img;
+    const int gy = rem / tgx, gx = rem - gy * tgx;
+    (void)n_tg;
+    const int tn = lane & 15, kq = lane >> 4, tr = tn >> 2, tc = tn & 3;
+    auto key = [](int pr, int pc) { return 2 * ((pc + 4 * (pr & 1)) & 7); };
 
-    // ---- epilogue vectors of every output channel -> LDS (visible after the first barrier below)
-    for (int e = tid; e < 12 * Cout; e += 256) {
-        const int a = e / Cout, co = e - a * Cout;
-        float v = 0.f;
-        if (a < 9) { if (p.bias && (a == 0 || p.bias_cls)) v = p.bias[a * Cout + co]; }
-        else if (a == 9) v = p.act == (int)Act::PRELU ? p.slope[co] : 1.f;
-        else if (p.out2) v = a == 10 ? p.s2[co] : p.t2[co];
-        ep[e] = v;
-    }
-    // ---- loader constants: pass i fills LDS row i * 32 + (tid >> 3), physical column tid & 7 <- patch pixel (dy, dx) of group g, logical column lc
-    unsigned lcst[NP];                                                     // dy | dx << 4 | lc << 9 | g << 12 | valid << 13
+    // ---- halo: 25 pieces of 4 LDS rows (= pixels) x 16 columns; lane -> row 4 i + (lane >> 4), physical column lane & 15
     {
-        const int col = tid & 7;
+        const int col = lane & 15;
+        const float* const img = p.in + (size_t)gn * H * W * 64;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int R = i * 32 + (tid >> 3);
-            const int g = R / RPT, rr = R - g * RPT;
-            const int pl = rr / (PH * PW), r2 = rr - pl * (PH * PW);
-            const int pr = r2 / PW, pc = r2 - pr * PW;
-            const int dy = 2 * pr + (pl >> 1), dx = 2 * pc + (pl & 1), lc = col ^ row_key<TGC>(pl, pr, pc);
-            lcst[i] = g < 2 ? (unsigned)(dy | dx << 4 | lc << 9 | g << 12 | 1 << 13) : 0u;
+        for (int i = 0; i < 25; ++i) {
+            const int R = 4 * i + (lane >> 4);
+            const int pl = R / 25, r2 = R - pl * 25, pr = r2 / 5, pc = r2 - pr * 5;
+            const int y = 8 * gy - 1 + 2 * pr + (pl >> 1), x = 8 * gx - 1 + 2 * pc + (pl & 1);
+            const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            dma16(ok ? img + ((size_t)y * W + x) * 64 + ((col ^ key(pr, pc)) << 2) : p.zeros, halo + i * 1024);
         }
     }
-    const int t = lane & 31, h = lane >> 5;
-    int tr, tc; bool live;
-    lane_tile<TGC>(t, tr, tc, live);
     typedef const __attribute__((address_space(3))) v4f* lds_v4f;
     const unsigned halo_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)halo;
     unsigned rb[16];
@@ -431,175 +401,167 @@ __global__ __launch_bounds__(256, 2) void wino2p_kernel(const ConvArgs p, const 
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx) {
             const int pl = (dy & 1) * 2 + (dx & 1), pr = tr + (dy >> 1), pc = tc + (dx >> 1);
-            const int R = tgi * RPT + (pl * PH + pr) * PW + pc;
-            rb[dy * 4 + dx] = halo_base + (unsigned)(R * 128 + ((row_key<TGC>(pl, pr, pc) ^ h) << 4));
+            rb[dy * 4 + dx] = halo_base + (unsigned)(((pl * 5 + pr) * 5 + pc) * 256 + ((key(pr, pc) ^ kq) << 4));
         }
-
-    // ---- per block: coordinates of its two tile groups (scalars) and the halo source offsets of this lane's loader passes
-    int gn[2], ggy[2], ggx[2], pair = 0, tile_n = 0;
-    unsigned a_off[NP];
-    auto locate = [&](int b) __attribute__((always_inline)) {
-        tile_n = b % tiles_n; pair = b / tiles_n;
-        const int tg0 = 2 * pair;
-        const int n = tg0 / per_img, rem = tg0 - n * per_img;
-        const int gy = rem / tgx;
-        gn[0] = __builtin_amdgcn_readfirstlane(n); ggy[0] = __builtin_amdgcn_readfirstlane(gy); ggx[0] = __builtin_amdgcn_readfirstlane(rem - gy * tgx);
-        gn[1] = gn[0]; ggy[1] = ggy[0]; ggx[1] = ggx[0] + 1;
-        if (ggx[1] == tgx) { ggx[1] = 0; if (++ggy[1] == tgy) { ggy[1] = 0; ++gn[1]; } }
-        const bool has1 = tg0 + 1 < n_tg;
+    // weights of this column tile: step (f, j) = CB KB at ((f * 4 + j) * CB) * 256 floats; cb-th fragment + cb * 256
+    // (a wave-uniform running pointer + the lane's 16-byte offset: with compile-time step offsets the 64 step addresses are hoisted out of
+    //  the loop into 128 registers)
+    const char* wstep = reinterpret_cast<const char*>(p.wt + (size_t)tile_n * 64 * CB * 256);
+    const unsigned wlane = lane * 16;
+    constexpr int WD = 4;                                                  // weight ring: fragments are requested WD - 1 steps (512 MFMA cycles each) ahead —
+    v4f wr[WD][CB] = {};                                                   // one step ahead left an L2 round trip under load exposed at every step (-12 %)
+#ifdef FACEHIP_W2_PROF
+    const bool abl_w = p.sk_test_drop & 4, abl_d = p.sk_test_drop & 8, abl_y = p.sk_test_drop & 16, abl_st = p.sk_test_drop & 2;   // ablations (wrong results)
+#else
+    constexpr bool abl_w = false, abl_d = false, abl_y = false, abl_st = false;
+#endif
+    auto fetch_w = [&](bool advance, int buf) __attribute__((always_inline)) {
+        if (abl_w) return;
+        unsigned adv = advance ? CB * 1024 : 0;
+        asm volatile("" : "+s"(adv));
+        wstep += adv;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const unsigned cst = lcst[i];
-            const int g = (cst >> 12) & 1;
-            const int y = 8 * (g ? ggy[1] : ggy[0]) - 1 + (int)(cst & 15), x = 2 * TGC * (g ? ggx[1] : ggx[0]) - 1 + (int)((cst >> 4) & 31);
-            const bool ok = (cst >> 13) && (g == 0 || has1) && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            a_off[i] = ok ? (unsigned)((((size_t)(g ? gn[1] : gn[0]) * H + y) * W + x) * Cin + ((cst >> 9) & 7) * 4) : ~0u;
-        }
+        for (int cb = 0; cb < CB; ++cb) wr[buf][cb] = *reinterpret_cast<const v4f*>(wstep + wlane + cb * 1024);
     };
-    auto load_halo = [&](int c) __attribute__((always_inline)) {
+    v4f Y[2][2][CB], Mp[CB];
 #pragma unroll
-        for (int i = 0; i < NP; ++i) dma16(a_off[i] != ~0u ? p.in + a_off[i] + c * 32 : p.zeros, halo + (i * 32 + wid * 8) * 128);
-    };
-
-    v16f Y[2][2];
-    auto y_update = [&](auto fc, const v16f& M) __attribute__((always_inline)) {
+    for (int cb = 0; cb < CB; ++cb) {
+        Mp[cb] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) Y[a >> 1][a & 1][cb] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    auto y_update = [&](auto fc, const v4f (&M)[CB]) __attribute__((always_inline)) {
         constexpr int f = decltype(fc)::value, i = f >> 2, j = f & 3;
+        if (abl_y && f != 5) return;
         constexpr int c00 = kAT[0][i] * kAT[0][j], c01 = kAT[0][i] * kAT[1][j], c10 = kAT[1][i] * kAT[0][j], c11 = kAT[1][i] * kAT[1][j];
-        if constexpr (c00 > 0) Y[0][0] += M; else if constexpr (c00 < 0) Y[0][0] -= M;
-        if constexpr (c01 > 0) Y[0][1] += M; else if constexpr (c01 < 0) Y[0][1] -= M;
-        if constexpr (c10 > 0) Y[1][0] += M; else if constexpr (c10 < 0) Y[1][0] -= M;
-        if constexpr (c11 > 0) Y[1][1] += M; else if constexpr (c11 < 0) Y[1][1] -= M;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            if constexpr (c00 > 0) Y[0][0][cb] += M[cb]; else if constexpr (c00 < 0) Y[0][0][cb] -= M[cb];
+            if constexpr (c01 > 0) Y[0][1][cb] += M[cb]; else if constexpr (c01 < 0) Y[0][1][cb] -= M[cb];
+            if constexpr (c10 > 0) Y[1][0][cb] += M[cb]; else if constexpr (c10 < 0) Y[1][0][cb] -= M[cb];
+            if constexpr (c11 > 0) Y[1][1][cb] += M[cb]; else if constexpr (c11 < 0) Y[1][1][cb] -= M[cb];
+            // pinned here: pure arithmetic floats freely in this barrier-free kernel, and left alone the scheduler defers the updates —
+            // every deferred frequency keeps its 4 CB accumulator registers alive (256 registers + spills by the tenth frequency)
+            if constexpr (c00 != 0) asm volatile("" : "+v"(Y[0][0][cb]));
+            if constexpr (c01 != 0) asm volatile("" : "+v"(Y[0][1][cb]));
+            if constexpr (c10 != 0) asm volatile("" : "+v"(Y[1][0][cb]));
+            if constexpr (c11 != 0) asm volatile("" : "+v"(Y[1][1][cb]));
+        }
     };
-    const int NC = Cin >> 5, NS = NC * 16;
-    v16f Mprev;
-    v4f d[2][4];
-    auto fetch_d = [&](auto fc, auto gc, auto bc) __attribute__((always_inline)) {
-        constexpr int f = decltype(fc)::value, g = decltype(gc)::value, buf = decltype(bc)::value;
+    v4f d[2][4] = {};
+    auto fetch_d = [&](auto fc, auto jc, auto bc) __attribute__((always_inline)) {
+        constexpr int f = decltype(fc)::value, j = decltype(jc)::value, buf = decltype(bc)::value;
         constexpr int fi = f >> 2, fj = f & 3;
         constexpr int ya = kYA[fi], yb = kYB[fi], xa = kYA[fj], xb = kYB[fj];
-        unsigned gx = g << 5;                                              // (opaque scalar: see wino2_kernel)
-        if constexpr (g > 0) asm volatile("" : "+s"(gx));
-        d[buf][0] = *reinterpret_cast<lds_v4f>((size_t)(rb[ya * 4 + xa] ^ gx));
-        d[buf][1] = *reinterpret_cast<lds_v4f>((size_t)(rb[ya * 4 + xb] ^ gx));
-        d[buf][2] = *reinterpret_cast<lds_v4f>((size_t)(rb[yb * 4 + xa] ^ gx));
-        d[buf][3] = *reinterpret_cast<lds_v4f>((size_t)(rb[yb * 4 + xb] ^ gx));
+        if (abl_d) return;
+        unsigned gxr = j << 6;                                             // k-step group j = columns 4 j .. 4 j + 3 (opaque: see wino2_kernel;
+        asm volatile("" : "+s"(gxr));                                      //  for j = 0 too: reads that depend on nothing are hoisted stages ahead)
+        d[buf][0] = *reinterpret_cast<lds_v4f>((size_t)(rb[ya * 4 + xa] ^ gxr));
+        d[buf][1] = *reinterpret_cast<lds_v4f>((size_t)(rb[ya * 4 + xb] ^ gxr));
+        d[buf][2] = *reinterpret_cast<lds_v4f>((size_t)(rb[yb * 4 + xa] ^ gxr));
+        d[buf][3] = *reinterpret_cast<lds_v4f>((size_t)(rb[yb * 4 + xb] ^ gxr));
     };
-    v4f wr[2][4];
-    const float* wg_src = nullptr;                                         // this wave's 4 KB of stage 0 of the current column tile
-    auto fetch_w = [&](int s, int buf) __attribute__((always_inline)) {
-        const float* src = wg_src + (size_t)s * 2048;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) wr[buf][g] = *reinterpret_cast<const v4f*>(src + g * 256);
-    };
-    int c = 0;
     auto stage = [&](auto fc) __attribute__((always_inline)) {
         constexpr int f = decltype(fc)::value;
         constexpr int fi = f >> 2, fj = f & 3;
-        constexpr int saa = kSA[fi] * kSA[fj], sab = kSA[fi] * kSB[fj], sba = kSB[fi] * kSA[fj], sbb = kSB[fi] * kSB[fj];
-        fetch_w(min(c * 16 + f + 1, NS - 1), (f + 1) & 1);                 // (the very last stage re-fetches itself: no branch in the loop body)
-        v16f M;
+        constexpr int sab = kSA[fi] * kSB[fj], sba = kSB[fi] * kSA[fj], sbb = kSB[fi] * kSB[fj];
+        v4f M[CB];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) M[e] = 0.f;
-        auto step = [&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value, k = f * 4 + g;
-            if constexpr (g < 3) fetch_d(IC<f>{}, IC<g + 1>{}, IC<(k + 1) & 1>{});
+        for (int cb = 0; cb < CB; ++cb) M[cb] = v4f{0.f, 0.f, 0.f, 0.f};
+        auto step = [&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value, k = f * 4 + j;
+            fetch_w(k + WD - 1 < 64, (k + WD - 1) % WD);                    // fragments of step k + WD - 1 (past the end: a harmless re-fetch)
+            if constexpr (j < 3) fetch_d(IC<f>{}, IC<j + 1>{}, IC<(k + 1) & 1>{});
             else if constexpr (f < 15) fetch_d(IC<f + 1>{}, IC<0>{}, IC<(k + 1) & 1>{});
             __builtin_amdgcn_sched_barrier(0);
             const v4f* dd = d[k & 1];
-            v4f v = saa > 0 ? dd[0] : -dd[0];
+            v4f v = dd[0];
             v = sab > 0 ? v + dd[1] : v - dd[1];
             v = sba > 0 ? v + dd[2] : v - dd[2];
             v = sbb > 0 ? v + dd[3] : v - dd[3];
             asm volatile("" : "+v"(v));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) M = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[f & 1][g][e], v[e], M, 0, 0, 0);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb) M[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[k % WD][cb][e], v[e], M[cb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         };
-        step(IC<0>{}); step(IC<1>{}); step(IC<2>{}); step(IC<3>{});
-        y_update(IC<(f + 15) & 15>{}, Mprev);
-        Mprev = M;
+        step(IC<0>{}); step(IC<1>{});
+        y_update(IC<(f + 15) & 15>{}, Mp);                                 // the previous frequency's result -> the outputs, in the shadow of this one's MFMAs
+        step(IC<2>{}); step(IC<3>{});
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) Mp[cb] = M[cb];
         __builtin_amdgcn_sched_barrier(0);
     };
+    fetch_w(false, 0);
+#pragma unroll
+    for (int q = 1; q < WD - 1; ++q) fetch_w(true, q);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the halo has landed: LDS-DMA is ordered for its own wave by vmcnt alone
+    fetch_d(IC<0>{}, IC<0>{}, IC<0>{});
+    stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{}); stage(IC<4>{}); stage(IC<5>{}); stage(IC<6>{}); stage(IC<7>{});
+    stage(IC<8>{}); stage(IC<9>{}); stage(IC<10>{}); stage(IC<11>{}); stage(IC<12>{}); stage(IC<13>{}); stage(IC<14>{}); stage(IC<15>{});
+    y_update(IC<15>{}, Mp);
 
-    locate(blk);
-    wg_src = p.wt + (size_t)tile_n * (Cin >> 5) * 16 * 2048 + (mb * 4 * 64 + lane) * 4;
-    load_halo(0);
-    fetch_w(0, 0);
-    __syncthreads();                                                       // first halo chunk landed; epilogue vectors visible
-    const bool relu = p.act == (int)Act::RELU;
-    const int cl0 = 32 * mb + 4 * h;                                       // channel within the column tile (accumulator quad 0)
-    for (;;) {
+    // ---- epilogue: lane = tile (tr, tc), accumulator block cb = channels 16 cb + 4 kq .. + 3 of the column tile
+    // (the kernel has no barrier, i.e. it is ONE basic block: without this fence the epilogue's bias / slope / residual loads are scheduled
+    //  in front of the K loop and their ~80 destination registers are spilled through it)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (abl_st && lane != 77) return;
+    const int oy0 = 2 * (4 * gy + tr), ox0 = 2 * (4 * gx + tc);
+    const int n0 = tile_n * 16 * CB, Cout = p.Cout;
+    const float* __restrict__ res = p.res;
+    float* __restrict__ out1 = p.out1;
+    float* __restrict__ out2 = p.out2;
+    const bool relu = p.act == (int)Act::RELU, prelu = p.act == (int)Act::PRELU;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b) {
+            const int oy = oy0 + a, ox = ox0 + b;
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            const size_t pix = ((size_t)gn * p.Ho + oy) * p.Wo + ox;
+            const int cls = p.bias_cls ? 3 * (oy == 0 ? 0 : oy == p.Ho - 1 ? 2 : 1) + (ox == 0 ? 0 : ox == p.Wo - 1 ? 2 : 1) : 0;
+            if constexpr (CB == 2) {                                       // merged sibling convolutions (the only CB = 2 users): per-channel-range destination and activation
 #pragma unroll
-                for (int e = 0; e < 16; ++e) Y[a][b][e] = 0.f;
+                for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) Mprev[e] = 0.f;
-        for (c = 0; c < NC; ++c) {
-            if (c > 0) {
-                __syncthreads();                                           // every wave is done with the previous chunk's halo
-                load_halo(c);
-                __syncthreads();                                           // (drains vmcnt: the chunk has landed)
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = n0 + 16 * cb + 4 * kq + e;
+                        if (co >= Cout) continue;
+                        const int g = co >= p.oc0[2] && p.n_outs > 2 ? 2 : co >= p.oc0[1] ? 1 : 0;
+                        const int cg = p.oc0[g + 1] - p.oc0[g];
+                        float v = Y[a][b][cb][e] + p.bias[cls * Cout + co];
+                        const int ga = p.oact[g];
+                        v = ga == (int)Act::RELU ? fmaxf(v, 0.f) : ga == (int)Act::SIGMOID ? 1.0f / (1.0f + expf(-v)) : v;
+                        p.outs[g][pix * cg + (co - p.oc0[g])] = v;
+                    }
+                continue;
             }
-            fetch_d(IC<0>{}, IC<0>{}, IC<0>{});
-            stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{}); stage(IC<4>{}); stage(IC<5>{}); stage(IC<6>{}); stage(IC<7>{});
-            stage(IC<8>{}); stage(IC<9>{}); stage(IC<10>{}); stage(IC<11>{}); stage(IC<12>{}); stage(IC<13>{}); stage(IC<14>{}); stage(IC<15>{});
-        }
-        y_update(IC<15>{}, Mprev);
-        __syncthreads();                                                   // every wave is done reading this block's halo
-        // this block's epilogue coordinates, then the NEXT block's halo + first weights go out in front of the epilogue
-        const int e_n = gn[tgi], e_gy = ggy[tgi], e_gx = ggx[tgi], e_n0 = tile_n * 64;
-        const bool e_live = live && 2 * pair + tgi < n_tg;
-        const int nxt = blk + blk_step;
-        const bool more = nxt < blk_end;
-        if (more) {
-            locate(nxt);
-            wg_src = p.wt + (size_t)tile_n * (Cin >> 5) * 16 * 2048 + (mb * 4 * 64 + lane) * 4;
-            load_halo(0);
-            fetch_w(0, 0);
-        }
-        if (e_live) {
-            const int oy0 = 2 * (4 * e_gy + tr), ox0 = 2 * (TGC * e_gx + tc);
-            const float* __restrict__ res = p.res;
-            float* __restrict__ out1 = p.out1;
-            float* __restrict__ out2 = p.out2;
-            const float* const epc = ep + e_n0 + cl0;
+            if constexpr (CB == 2) continue;                               // (the vector epilogue below is the CB = 4 form's)
+            const size_t row = pix * Cout + n0 + 4 * kq;
+            v4f r4[CB];
+            if (p.res_mode != (int)ResMode::NONE) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+                for (int cb = 0; cb < CB; ++cb) r4[cb] = *reinterpret_cast<const v4f*>(res + row + 16 * cb);
+            }
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int oy = oy0 + a, ox = ox0 + b;
-                    if (oy >= p.Ho || ox >= p.Wo) continue;
-                    const size_t row = (((size_t)e_n * p.Ho + oy) * p.Wo + ox) * Cout + e_n0 + cl0;
-                    const int cls = p.bias_cls ? 3 * (oy == 0 ? 0 : oy == p.Ho - 1 ? 2 : 1) + (ox == 0 ? 0 : ox == p.Wo - 1 ? 2 : 1) : 0;
-                    v4f r4[4];
-                    if (p.res_mode != (int)ResMode::NONE) {
+            for (int cb = 0; cb < CB; ++cb) {
+                const int co = n0 + 16 * cb + 4 * kq;
+                const v4f b4 = p.bias ? *reinterpret_cast<const v4f*>(p.bias + cls * Cout + co) : v4f{0.f, 0.f, 0.f, 0.f};
+                const v4f sl = prelu ? *reinterpret_cast<const v4f*>(p.slope + co) : v4f{1.f, 1.f, 1.f, 1.f};
+                v4f v;
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) r4[q] = *reinterpret_cast<const v4f*>(res + row + 8 * q);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const v4f b4 = *reinterpret_cast<const v4f*>(epc + cls * Cout + 8 * q);
-                        const v4f sl = *reinterpret_cast<const v4f*>(epc + 9 * Cout + 8 * q);
-                        v4f v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = act1(Y[a][b][4 * q + e] + b4[e], relu, sl[e]);
-                        if (p.res_mode != (int)ResMode::NONE) v += r4[q];
-                        if (out1) *reinterpret_cast<v4f*>(out1 + row + 8 * q) = v;
-                        if (out2) {
-                            const v4f s2 = *reinterpret_cast<const v4f*>(epc + 10 * Cout + 8 * q), t2 = *reinterpret_cast<const v4f*>(epc + 11 * Cout + 8 * q);
-                            *reinterpret_cast<v4f*>(out2 + row + 8 * q) = v * s2 + t2;
-                        }
-                    }
+                for (int e = 0; e < 4; ++e) v[e] = act1(Y[a][b][cb][e] + b4[e], relu, sl[e]);
+                if (p.res_mode != (int)ResMode::NONE) v += r4[cb];
+                if (out1) *reinterpret_cast<v4f*>(out1 + row + 16 * cb) = v;
+                if (out2) {
+                    const v4f s2 = *reinterpret_cast<const v4f*>(p.s2 + co), t2 = *reinterpret_cast<const v4f*>(p.t2 + co);
+                    *reinterpret_cast<v4f*>(out2 + row + 16 * cb) = v * s2 + t2;
                 }
+            }
         }
-        if (!more) break;
-        blk = nxt;
-        __syncthreads();                                                   // the next block's first halo chunk has landed
-    }
 }
 
 int pick_tgc(int W) {
@@ -608,55 +570,41 @@ int pick_tgc(int W) {
     return g7 < g8 ? 7 : 8;
 }
 
-int wreg_mode() {
+int x16_mode() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("FACEHIP_WINO2_WREG"); v = e ? atoi(e) : 1; }   // (0 = weights through the shared LDS stage: A / B timing)
+    if (v < 0) { const char* e = getenv("FACEHIP_WINO2_X16"); v = e ? atoi(e) : 1; }    // (0 = the 32-column kernel for 64-channel layers too: A / B timing)
     return v;
 }
+// layers the 16-column kernel takes: exactly 64 input channels; 64 k output channels, or <= 32 (SCRFD's merged head convolutions)
+bool x16_shape(int Cin, int Cout) { return x16_mode() && Cin == 64 && (Cout % 64 == 0 || Cout <= 32); }   // (<= 32: merged outputs only, see wino2_ok)
 
-int persist_mode() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("FACEHIP_WINO2_PERSIST"); v = e ? atoi(e) : 1; }   // (0 = one block per workgroup: A / B timing, phase stamps)
-    return v;
+template <int CB>
+void launch_x16(const ConvArgs& a, hipStream_t s) {
+    const int tgy = ((a.H + 1) / 2 + 3) / 4, tgx = ((a.W + 1) / 2 + 3) / 4;
+    const long n_tg = (long)a.B * tgy * tgx;
+    const int tiles_n = (a.Cout + 16 * CB - 1) / (16 * CB);
+    KernelTimer& timer = KernelTimer::get();
+    timer.begin(s);
+    hipLaunchKernelGGL((wino2x_kernel<CB>), dim3((unsigned)(n_tg * tiles_n)), dim3(64), 25600, s, a, tiles_n, tgx, tgy, (int)n_tg);
+    timer.end(s, 12, 2.0 * 16 * 16.0 * (double)n_tg * a.Cin * (16.0 * CB * tiles_n), a.t_flops);   // executed FLOPs (padded tiles / channels included)
 }
 
 template <int TGC>
-void launch_persistent(const ConvArgs& a, hipStream_t s) {
-    const int ht = (a.H + 1) / 2, wt = (a.W + 1) / 2;
-    const int tgy = (ht + 3) / 4, tgx = (wt + TGC - 1) / TGC;
-    const long n_tg = (long)a.B * tgy * tgx;
-    const int tiles_n = a.Cout / 64;
-    const long blocks = (n_tg + 1) / 2 * tiles_n;
-    const size_t lds = Geo<TGC>::HALO_BYTES + (size_t)12 * a.Cout * sizeof(float);
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino2p_kernel<TGC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
-    const int cus = a.cus > 0 ? a.cus : conv_num_cus();
-    const long grid = std::min<long>((blocks + 7) / 8 * 8, 2L * cus);          // two workgroups per CU, a multiple of the 8 XCDs
-    KernelTimer& timer = KernelTimer::get();
-    timer.begin(s);
-    hipLaunchKernelGGL((wino2p_kernel<TGC>), dim3((unsigned)grid), dim3(256), lds, s, a, tiles_n, tgx, tgy, (int)n_tg, (int)blocks);
-    timer.end(s, 12, 2.0 * 16 * 32.0 * (double)((n_tg + 1) / 2 * 2) * a.Cin * a.Cout, a.t_flops);   // (bytes slot: the layer's direct-form FLOPs, as tag 7)
-}
-
-template <int TGC, bool WREG>
 void launch_tgc(const ConvArgs& a, hipStream_t s) {
     const int ht = (a.H + 1) / 2, wt = (a.W + 1) / 2;
     const int tgy = (ht + 3) / 4, tgx = (wt + TGC - 1) / TGC;
     const long n_tg = (long)a.B * tgy * tgx;
     const int tiles_n = a.Cout / 64;
     const long blocks = (n_tg + 1) / 2 * tiles_n;
-    const size_t lds = Geo<TGC>::HALO_BYTES + (WREG ? 0 : 2 * 8192);
+    const size_t lds = Geo<TGC>::HALO_BYTES;
     static bool attr_done = false;
     if (!attr_done) {
-        FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino2_kernel<TGC, WREG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wino2_kernel<TGC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
-    hipLaunchKernelGGL((wino2_kernel<TGC, WREG>), dim3((unsigned)blocks), dim3(256), lds, s, a, tiles_n, tgx, tgy, (int)n_tg);
+    hipLaunchKernelGGL((wino2_kernel<TGC>), dim3((unsigned)blocks), dim3(256), lds, s, a, tiles_n, tgx, tgy, (int)n_tg);
     // booked with the FLOPs the matrix cores EXECUTE (16 products per 2x2 tile and channel pair, idle lanes included)
     timer.end(s, 12, 2.0 * 16 * 32.0 * (double)((n_tg + 1) / 2 * 2) * a.Cin * a.Cout, a.t_flops);   // (bytes slot: the layer's direct-form FLOPs, as tag 7)
 }
@@ -666,9 +614,34 @@ void launch_tgc(const ConvArgs& a, hipStream_t s) {
 // U_f = G g G^T per (output channel, input channel) in fp64, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], laid out in the order the kernel's
 // LDS stages and MFMA fragments want: [Cout / 64][Cin / 32][16 f][2 halves of 32 channels][4 k-groups][2 k-halves][32 rows][4 floats],
 // element = U_f[cout = 64 tn + 32 mb + m][cin = 32 c + 8 g + 4 kh + e].  w = [Cout][9 taps][Cin] (the engine's layout).
-size_t wino2_weight_floats(int Cin, int Cout) { return (size_t)16 * Cin * Cout; }
+// 16-column kernel (Cin = 64): [column tile][16 f][4 j][CB blocks of 16 channels][64 lanes (m = lane & 15, kq = lane >> 4)][4 floats],
+// element = U_f[cout = 16 CB tn + 16 cb + m][cin = 16 j + 4 kq + e]; channels >= Cout are zero rows.
+size_t wino2_weight_floats(int Cin, int Cout) {
+    if (x16_shape(Cin, Cout)) return (size_t)16 * Cin * (Cout <= 32 ? 32 : Cout);
+    return (size_t)16 * Cin * Cout;
+}
 void wino2_pack_weights(const float* w, int Cout, int Cin, float* dst) {
     static const double Gm[4][3] = {{1, 0, 0}, {.5, .5, .5}, {.5, -.5, .5}, {0, 0, 1}};
+    if (x16_shape(Cin, Cout)) {
+        const int CB = Cout <= 32 ? 2 : 4;
+        memset(dst, 0, wino2_weight_floats(Cin, Cout) * sizeof(float));
+        for (int co = 0; co < Cout; ++co)
+            for (int ci = 0; ci < Cin; ++ci) {
+                double g[3][3], t[4][3];
+                for (int k = 0; k < 9; ++k) g[k / 3][k % 3] = w[((size_t)co * 9 + k) * Cin + ci];
+                for (int i = 0; i < 4; ++i)
+                    for (int x = 0; x < 3; ++x) t[i][x] = Gm[i][0] * g[0][x] + Gm[i][1] * g[1][x] + Gm[i][2] * g[2][x];
+                const int tn = co / (16 * CB), cb = (co % (16 * CB)) / 16, m = co % 16;
+                const int j = ci / 16, kq = (ci % 16) / 4, e = ci % 4;
+                for (int i = 0; i < 4; ++i)
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const double u = t[i][0] * Gm[jj][0] + t[i][1] * Gm[jj][1] + t[i][2] * Gm[jj][2];
+                        const size_t step = ((size_t)tn * 16 + (i * 4 + jj)) * 4 + j;
+                        dst[(step * CB + cb) * 256 + (kq * 16 + m) * 4 + e] = (float)u;
+                    }
+            }
+        return;
+    }
     const int NC = Cin / 32;
     for (int co = 0; co < Cout; ++co)
         for (int ci = 0; ci < Cin; ++ci) {
@@ -688,9 +661,13 @@ void wino2_pack_weights(const float* w, int Cout, int Cin, float* dst) {
 }
 
 bool wino2_ok(const ConvArgs& a) {
-    return a.ks == 3 && a.stride == 1 && a.pad == 1 && a.H == a.Ho && a.W == a.Wo && a.H >= 2 && a.W >= 2 && a.Cin % 32 == 0 && a.Cin >= 32 &&
-           a.Cout % 64 == 0 && a.act != (int)Act::SIGMOID && a.n_outs == 0 && !a.sc_in && !a.dw_w && !a.u8_src && a.wt_group_rows == 0 &&
-           (a.res_mode == (int)ResMode::NONE || a.res_mode == (int)ResMode::SAME);
+    if (!(a.ks == 3 && a.stride == 1 && a.pad == 1 && a.H == a.Ho && a.W == a.Wo && a.H >= 2 && a.W >= 2 && a.Cin % 32 == 0 && a.Cin >= 32 &&
+          a.act != (int)Act::SIGMOID && !a.sc_in && !a.dw_w && !a.u8_src && a.wt_group_rows == 0 &&
+          (a.res_mode == (int)ResMode::NONE || a.res_mode == (int)ResMode::SAME)))
+        return false;
+    if (a.n_outs > 0)                                                      // merged sibling convolutions: the 16-column kernel's epilogue only
+        return x16_shape(a.Cin, a.Cout) && a.Cout <= 32 && a.res_mode == (int)ResMode::NONE && !a.out2 && !a.bias_cls;
+    return a.Cout % 64 == 0;                                               // (plain layers: whole 64-channel column tiles)
 }
 
 // diagnostic builds (-DFACEHIP_W2_PROF, scripts/wino2_prof.sh): device buffer the kernel's phase stamps go to (1 MB, allocated on first use)
@@ -701,6 +678,8 @@ const void* wino2_stamp_buffer() {
 }
 
 long wino2_blocks(const ConvArgs& a) {
+    if (x16_shape(a.Cin, a.Cout))                                          // one-wave workgroups: counted in units of four (a 256-thread workgroup's worth)
+        return (long)a.B * (((a.H + 1) / 2 + 3) / 4) * (((a.W + 1) / 2 + 3) / 4) * ((a.Cout + 63) / 64) / 4;
     const int tgc = pick_tgc(a.W);
     const long n_tg = (long)a.B * (((a.H + 1) / 2 + 3) / 4) * (((a.W + 1) / 2 + tgc - 1) / tgc);
     return (n_tg + 1) / 2 * (a.Cout / 64);
@@ -713,13 +692,12 @@ void launch_wino2(const ConvArgs& a_in, hipStream_t s) {
     a.zeros = conv_zero_line();
     a.slabs = g_w2_stamps;                                                 // (null unless a diagnostic run asked for the stamp buffer)
     { const char* e = getenv("FACEHIP_W2_ABLATE"); a.sk_test_drop = e ? atoi(e) : 0; }   // (read by diagnostic builds only)
-    if (persist_mode() && a.Cout <= 512) {
-        if (pick_tgc(a.W) == 7) launch_persistent<7>(a, s); else launch_persistent<8>(a, s);
+    if (x16_shape(a.Cin, a.Cout)) {
+        if (a.Cout <= 32) launch_x16<2>(a, s); else launch_x16<4>(a, s);
         return;
     }
-    const bool wreg = wreg_mode() != 0;
-    if (pick_tgc(a.W) == 7) { if (wreg) launch_tgc<7, true>(a, s); else launch_tgc<7, false>(a, s); }
-    else { if (wreg) launch_tgc<8, true>(a, s); else launch_tgc<8, false>(a, s); }
+    if (pick_tgc(a.W) == 7) launch_tgc<7>(a, s);
+    else launch_tgc<8>(a, s);
 }
 
 }  // namespace fh

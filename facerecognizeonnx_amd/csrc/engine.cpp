@@ -182,10 +182,13 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
             }
             // fused Winograd F(2x2,3x3) image (conv_wino2.hip) for the 3x3 stride-1 convolutions below the F(4x4) threshold: the weights
             // here already carry the block's folded BatchNorm (loop above), whose 9 bias classes the kernel's epilogue applies
-            if (op.kind == OpKind::CONV && op.Cin < kWinoMinCin && op.outs.empty()) {
+            if (op.kind == OpKind::CONV && op.Cin < kWinoMinCin) {           // (merged sibling convolutions too: SCRFD's 64 -> 30 head convolutions)
                 ConvArgs probe{};
                 probe.ks = op.ks; probe.stride = op.stride; probe.pad = op.pad; probe.Cin = op.Cin; probe.Cout = op.Cout; probe.act = (int)op.act;
                 probe.res_mode = (int)op.res_mode; probe.H = op.H; probe.W = op.W; probe.Ho = op.Ho; probe.Wo = op.Wo;
+                probe.n_outs = (int)op.outs.size(); probe.bias_cls = dev_[i].bn_fold_src >= 0 ? 1 : 0;
+                float dummy2 = 0.f;
+                probe.out2 = op.out2 >= 0 ? &dummy2 : nullptr;
                 if (wino2_ok(probe)) {
                     std::vector<float> u(wino2_weight_floats(op.Cin, op.Cout));
                     wino2_pack_weights(op.weight.data(), op.Cout, op.Cin, u.data());

@@ -7,8 +7,8 @@ B=build/facehip
 OBJS=$(ls $B/*.o | grep -v "conv_wino2.o" | grep -v "_prof.o")
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o /tmp/libfacehip_w2prof.so $OBJS $B/conv_wino2_prof.o -lz
 for shape in "${@:-56 56 64 64}"; do
-  for wreg in 1 0; do for abl in 0 1 2 3; do
-    echo "== $shape  weights via registers=$wreg  ablation=$abl (1 = no halo DMA, 2 = no epilogue memory traffic)"
-    FACEHIP_WINO2_WREG=$wreg FACEHIP_W2_ABLATE=$abl FACEHIP_LIB=/tmp/libfacehip_w2prof.so python scripts/wino2_prof.py $shape 2>&1 | grep -v amdgpu.ids
-  done; done
+  for abl in 0 2 4 8 16 30; do
+    echo "== $shape  ablation=$abl (bits: 1 = no halo DMA (32-column kernel), 2 = no epilogue traffic, 4 = no weight loads, 8 = no patch reads, 16 = no output updates)"
+    FACEHIP_W2_ABLATE=$abl FACEHIP_LIB=/tmp/libfacehip_w2prof.so python scripts/wino2_prof.py $shape 2>&1 | grep -v amdgpu.ids
+  done
 done
