@@ -783,7 +783,7 @@ int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi, const float* d_
 // [cout][3*3][cin]; d_bias [cout] or, with bias_cls, [9][cout]; act = fh::Act; d_slope / d_res optional
 int fh_conv_wino2_dev(const float* d_in, const float* w_ohwi, const float* d_bias, const float* d_slope, const float* d_res, float* d_out,
                       int batch, int h, int w, int cin, int cout, int act, int bias_cls, void* stream) {
-    if (!d_in || !w_ohwi || !d_out || cin % 32 || cout % 64) return arg_error("fh_conv_wino2_dev: bad argument");
+    if (!d_in || !w_ohwi || !d_out || cin != 64 || cout % 64) return arg_error("fh_conv_wino2_dev: bad argument (cin = 64, cout % 64 == 0)");
     return guarded([&] {
         std::vector<float> u(fh::wino2_weight_floats(cin, cout));
         fh::wino2_pack_weights(w_ohwi, cout, cin, u.data());
@@ -800,7 +800,6 @@ int fh_conv_wino2_dev(const float* d_in, const float* w_ohwi, const float* d_bia
         return 0;
     });
 }
-const void* fh_debug_wino2_stamps(void) { return fh::wino2_stamp_buffer(); }
 int fh_conv_wt_rows(int cout) { return fh::conv_wt_rows(cout); }
 int fh_conv_pack_weights(const float* w_ohwi, int cout, int cin, int ksize, float* dst_packed) {
     if (!w_ohwi || !dst_packed || cout <= 0 || cin <= 0) return arg_error("fh_conv_pack_weights: bad argument");

@@ -114,14 +114,13 @@ bool conv_take_error(std::string& msg);
 unsigned conv_error_generation();
 void conv_debug_streamk(int drop_publish, int timeout_ms);
 unsigned conv_debug_generation();             // bumped by conv_debug_streamk (its settings are kernel arguments: captured graphs hold them)
-// Fused Winograd F(2x2, 3x3) for 3x3 stride-1 pad-1 convolutions with Cin % 32 == 0, Cout % 64 == 0 (conv_wino2.hip): a.wt = the
+// Fused Winograd F(2x2, 3x3) for 3x3 stride-1 pad-1 convolutions with Cin = 64 and Cout % 64 == 0 (or <= 32 with merged outputs) (conv_wino2.hip): a.wt = the
 // wino2_pack_weights image of the filter [Cout][9][Cin]; epilogue fields (bias / bias_cls, act, slope, res, out1, out2) as for launch_conv
 size_t wino2_weight_floats(int Cin, int Cout);
 void wino2_pack_weights(const float* w_ohwi, int Cout, int Cin, float* dst);
 bool wino2_ok(const ConvArgs& a);
 void launch_wino2(const ConvArgs& a, hipStream_t s);
 long wino2_blocks(const ConvArgs& a);          // workgroups the launch would have
-const void* wino2_stamp_buffer();              // diagnostic builds: where the kernel's phase stamps land (scripts/wino2_prof.sh)
 const float* conv_zero_line();                // 8 KiB of device zeros (target of padded / dead loads)
 int conv_num_cus();                           // compute units of the current device
 // dense 3x3 stride-1 convolutions with 16 input channels and <= 64 output channels on an 8x16 spatial tile with an LDS halo

@@ -241,14 +241,11 @@ FH_API int fh_conv_forward_dev(const float* d_in, const float* d_wt_packed, cons
  * [cout][3*3][cin]; cin % 32 == 0, cout % 4 == 0.  Synchronous. */
 FH_API int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi_host, const float* d_bias, float* d_out, int batch, int h, int w,
                                 int cin, int cout, void* stream);
-/* The same convolution in the fused Winograd F(2x2,3x3) form the 64-channel stages use (conv_wino2.hip): cin % 32 == 0, cout % 64 == 0;
+/* The same convolution in the fused Winograd F(2x2,3x3) form the 64-channel stages use (conv_wino2.hip): cin == 64, cout % 64 == 0;
  * d_bias = [cout] or, with bias_cls != 0, [9][cout] (one vector per border class of the output pixel: a pre-conv BatchNorm folded in);
  * act = 0 none / 1 ReLU / 2 PReLU (d_slope [cout]) ...; d_res = optional residual of the output's shape.  Synchronous. */
 FH_API int fh_conv_wino2_dev(const float* d_in, const float* w_ohwi_host, const float* d_bias, const float* d_slope, const float* d_res,
                              float* d_out, int batch, int h, int w, int cin, int cout, int act, int bias_cls, void* stream);
-/* Diagnostic builds of conv_wino2.hip (-DFACEHIP_W2_PROF, scripts/wino2_prof.sh): device buffer [workgroup][wave][8 x int64] its phase
- * stamps land in; allocated (1 MB) on the first call.  Production builds never write it. */
-FH_API const void* fh_debug_wino2_stamps(void);
 /* Batch-1 host-pointer calls (fh_det_detect, fh_rec_extract, fh_rec_extract_simple — the reference's own mode, src/main.cpp:88-104) are
  * captured into a HIP graph per call shape (image size / pitch, thresholds) and replayed: first call with a shape eager, second
  * captured, later ones one hipGraphLaunch each.  Results are bitwise those of the eager path.  fh_set_graph_replay(0) (or

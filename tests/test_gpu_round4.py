@@ -198,11 +198,11 @@ def test_align_equal_count_consensus_ties_match_oracle_bit_exact(models_dir):
 
 WINO2_CASES = [
     # B, H,   W,   Cin, Cout, act (0 none / 1 relu / 2 prelu), residual, 9 bias classes
-    (2, 56, 56, 64, 64, 2, True, True),        # IResNet stage 1 shape: 7-wide tile groups (28 tile columns), PReLU + residual, folded BatchNorm
-    (1, 112, 112, 64, 64, 2, False, True),     # the first block's conv: 8-wide tile groups (56 tile columns)
+    (2, 56, 56, 64, 64, 2, True, True),        # IResNet stage 1 shape: 7 x 7 tile groups, PReLU + residual, folded BatchNorm
+    (1, 112, 112, 64, 64, 2, False, True),     # the first block's conv
     (3, 56, 56, 64, 128, 0, False, False),     # two column tiles
-    (5, 13, 17, 32, 64, 1, True, False),       # odd map: ragged tile groups in x and y, one 32-channel chunk, an odd number of groups
-    (2, 30, 22, 96, 64, 2, True, True),        # three chunks; 11 tile columns -> 8-wide groups with a half-empty second group
+    (5, 13, 17, 64, 64, 1, True, False),       # odd map: ragged tile groups in x and y (half-empty groups, a last pixel row / column)
+    (2, 30, 22, 64, 192, 2, True, True),       # three column tiles; map sides off the 8-pixel grid
     (1, 2, 2, 64, 64, 0, False, True),         # a single tile
     (4, 80, 80, 64, 64, 1, False, False),      # SCRFD's head map size
 ]
@@ -211,6 +211,7 @@ WINO2_CASES = [
 @pytest.mark.parametrize("B,H,W,Cin,Cout,act,with_res,cls", WINO2_CASES)
 def test_wino2_fused_conv_layer_matches_oracle(B, H, W, Cin, Cout, act, with_res, cls):
     """The fused Winograd F(2x2,3x3) kernel (conv_wino2.hip) that takes the 3x3 stride-1 convolutions of w600k_r50's 64-channel stages
+    (and, through the network tests, SCRFD's merged 64 -> 30 head convolutions)
     (Conv nodes inside session_->Run, face_recognizer.cpp:279-283) against the oracle's direct fp32 convolution: bias per border class
     (the block's BatchNorm folded in), PReLU / ReLU, residual.  5e-5 absolute on O(1) outputs: F(2x2) rounds ~3x coarser than the direct
     form's 2e-5 bar (points 0, +-1, inf), far inside F(4x4)'s 2e-4."""

@@ -289,3 +289,16 @@ def test_planner_keeps_the_shortcut_input_alive_for_the_folded_form(tmp_path, ds
                 assert o2 + e2 <= off or off + elems <= o2, (src, t)
         links += 1
     assert links == 4                                                  # one per stage
+
+
+def test_wino2_layout_model_is_conflict_free_and_exact():
+    """CPU model of conv_wino2.hip's data movement (scripts/wino2_banks.py mirrors the kernel's index arithmetic one to one): every
+    ds_read_b128 of the K loop touches 16 different bank quads per service group, and the emulated kernel — swizzled parity planes,
+    lane -> tile map, packed weight order, F(2x2,3x3) transforms — equals a direct convolution (the Conv nodes of
+    face_recognizer.cpp:279-283's graph) to rounding, incl. ragged tile groups and the merged-head channel count."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("wino2_banks", os.path.join(ROOT, "scripts", "wino2_banks.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.bank_report() == (1, 1.0)
+    assert mod.emulate(1, 10, 13, 64) < 1e-12
+    assert mod.emulate(1, 8, 8, 30) < 1e-12
