@@ -7,7 +7,7 @@ import facerecognizeonnx_amd as fa
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 L = fa.lib(); L.fh_init(0)
 rng = np.random.default_rng(0)
-for (H, W, Cin, Cout) in ((56, 56, 64, 64), (112, 112, 64, 64), (56, 56, 64, 128), (28, 28, 128, 128), (80, 80, 64, 64)):
+for (H, W, Cin, Cout) in ((56, 56, 64, 64), (112, 112, 64, 64), (56, 56, 64, 128), (80, 80, 64, 64)):
     x = torch.from_numpy(rng.standard_normal((B, H, W, Cin)).astype(np.float32)).cuda()
     w0 = (rng.standard_normal((Cout, 9, Cin)) / np.sqrt(9 * Cin)).astype(np.float32)
     b = torch.zeros(Cout, device="cuda"); out = torch.zeros((B, H, W, Cout), device="cuda")
