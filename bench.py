@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--crops", type=int, default=256, help="--workload embed: pre-aligned crops per batch (config 2)")
     ap.add_argument("--score-thr", type=float, default=0.5)
     ap.add_argument("--nms-thr", type=float, default=0.4)
+    ap.add_argument("--as-rank", type=int, default=-1, help="--workload match on ONE GPU playing rank R of --of-world N of a row-sharded gallery "
+                    "(config C5's per-rank work: its shard only, uploaded with its global index base; no collective)")
+    ap.add_argument("--of-world", type=int, default=8)
     ap.add_argument("--stream-priority", default="rec", choices=["rec", "det", "none"],
                     help="streaming e2e form: which of the two HIP streams gets the higher priority (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -250,6 +253,8 @@ def bench_match(args, rank, world, local, dist, cdev, fa, torch):
     G = args.gallery or 1_000_000
     Q, k, dim = args.queries, args.topk, 512
     gb, ge = fd.gallery_shard_base(G, rank, world)
+    if args.as_rank >= 0 and world == 1:                 # one GPU plays rank R of N: C5's per-rank shard at its own size and index base
+        gb, ge = fd.gallery_shard_base(G, args.as_rank, args.of_world)
     gen = torch.Generator(device="cuda"); gen.manual_seed(4 + rank)
     gal = torch.randn((ge - gb, dim), device="cuda", generator=gen)
     gal /= gal.norm(dim=1, keepdim=True)
@@ -300,7 +305,9 @@ def bench_match(args, rank, world, local, dist, cdev, fa, torch):
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"C4 match stage: {Q} L2-normalised 512-d queries vs {G} gallery rows ({rows_local} on this rank), top-{k} "
                                       f"by (dot+1)/2", "gallery_rows": G, "queries": Q, "topk": k,
-                          "parallelism": f"gallery row-sharded x{world}" + (", one all-gather of per-rank top-k + kernel merge" if world > 1 else "")},
+                          "parallelism": f"gallery row-sharded x{world}" + (", one all-gather of per-rank top-k + kernel merge" if world > 1 else "") +
+                                         (f"; this GPU plays rank {args.as_rank} of {args.of_world} (rows [{gb}, {ge}), global indices; the exchange itself is not run)"
+                                          if args.as_rank >= 0 and world == 1 else "")},
                "roofline": None}
         # the scan is priced against whichever of its two floors is higher: every gallery row once from HBM (rows x dim x 4 B at 8 TB/s) or
         # 2 Q rows dim FLOP on the f32 matrix cores (157.3 TFLOP/s) — at Q = 64 the matrix cores bind (0.43 ms against 0.26 ms per 1 M rows)

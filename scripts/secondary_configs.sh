@@ -8,6 +8,7 @@ run c3_detect --workload detect
 run f4 --faces-per-frame 4
 run c4_gallery --gallery 1000000 --frames 64
 run c4_match --workload match --gallery 1000000 --queries 64 --topk 16
+run c5_rank --workload match --gallery 10000000 --as-rank 7 --of-world 8 --queries 64 --topk 16
 run from_host --from-host
 run serial --serial
 run latency --workload latency

@@ -8,6 +8,7 @@ rows = [("headline", "headline: 128 frames 640x640, detect+align+embed, F=1 (str
         ("f4", "headline with 4 faces per frame", "`--faces-per-frame 4`"),
         ("c4_gallery", "C4: 64 frames end-to-end + top-16 of a 1 M x 512 gallery", "`--gallery 1000000 --frames 64`"),
         ("c4_match", "C4 match stage alone: 64 queries vs 1 M x 512 gallery, top-16 (one scan kernel + list merge)", "`--workload match --gallery 1000000 --queries 64 --topk 16`"),
+        ("c5_rank", "C5 per-rank work on one GPU: the LAST of 8 shards of a 10 M x 512 gallery (1.25 M rows, index base 8.75 M), 64 queries, top-16 (the 8-rank exchange itself is not run)", "`--workload match --gallery 10000000 --as-rank 7 --of-world 8 --queries 64 --topk 16`"),
         ("from_host", "PCIe-inclusive headline (pinned host frames, double-buffered H2D)", "`--from-host`"),
         ("serial", "headline, one batch at a time on one stream (the default streams: detector of batch k+1 beside the recogniser of batch k)", "`--serial`"),
         ("latency", "batch-1 latency through the blocking C-ABI (`fh_det_detect` + `fh_rec_extract` from host memory, HIP-graph replay)", "`--workload latency`"),
