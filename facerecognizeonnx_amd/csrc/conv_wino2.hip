@@ -240,15 +240,29 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
+                    for (int e = 0; e < 4; e += 2) {                       // channel pairs: one 8-byte store where both land in one destination, aligned
                         const int co = n0 + 16 * cb + 4 * kq + e;
                         if (co >= Cout) continue;
                         const int g = co >= p.oc0[2] && p.n_outs > 2 ? 2 : co >= p.oc0[1] ? 1 : 0;
-                        const int cg = p.oc0[g + 1] - p.oc0[g];
-                        float v = Y[a][b][cb][e] + p.bias[cls * Cout + co];
-                        const int ga = p.oact[g];
-                        v = ga == (int)Act::RELU ? fmaxf(v, 0.f) : ga == (int)Act::SIGMOID ? 1.0f / (1.0f + expf(-v)) : v;
-                        p.outs[g][pix * cg + (co - p.oc0[g])] = v;
+                        const int cg = p.oc0[g + 1] - p.oc0[g], ga = p.oact[g];
+                        auto fin = [&](float v, int c) {
+                            v += p.bias[cls * Cout + c];
+                            return ga == (int)Act::RELU ? fmaxf(v, 0.f) : ga == (int)Act::SIGMOID ? 1.0f / (1.0f + expf(-v)) : v;
+                        };
+                        float* const dst = p.outs[g] + pix * cg + (co - p.oc0[g]);
+                        const float v0 = fin(Y[a][b][cb][e], co);
+                        if (co + 1 < p.oc0[g + 1] && !((cg | (co - p.oc0[g])) & 1)) {
+                            *reinterpret_cast<float2*>(dst) = float2{v0, fin(Y[a][b][cb][e + 1], co + 1)};
+                        } else {
+                            dst[0] = v0;
+                            if (co + 1 < Cout) {                          // the pair straddles two destinations (or is unaligned): scalar stores
+                                const int g1 = co + 1 >= p.oc0[2] && p.n_outs > 2 ? 2 : co + 1 >= p.oc0[1] ? 1 : 0;
+                                const int cg1 = p.oc0[g1 + 1] - p.oc0[g1], ga1 = p.oact[g1];
+                                float v1 = Y[a][b][cb][e + 1] + p.bias[cls * Cout + co + 1];
+                                v1 = ga1 == (int)Act::RELU ? fmaxf(v1, 0.f) : ga1 == (int)Act::SIGMOID ? 1.0f / (1.0f + expf(-v1)) : v1;
+                                p.outs[g1][pix * cg1 + (co + 1 - p.oc0[g1])] = v1;
+                            }
+                        }
                     }
                 continue;
             }

@@ -18,7 +18,7 @@ python3 - <<PY
 import csv, glob, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 def short(n):
-    n = re.sub(r"\(.*", "", n); n = n.replace("void ", "").replace("fh::", "")
+    n = n.replace("void ", "").replace("fh::", "").replace("(anonymous namespace)::", ""); n = re.sub(r"\(.*", "", n)
     return n[:70]
 for f in glob.glob("$R/gpurun_out/pmck_${TAG}_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
