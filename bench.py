@@ -38,7 +38,7 @@ CFG_NAMES = ["conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<256,64,4,1>", 
              "conv_igemm_kernel<64,64,2,2>", "dwpw_kernel (incl. the fused stem front) + dwconv3x3 kernels", "other graph ops (incl. stem_conv_u8)",
              "conv_fixup_kernel", "wino_gemm_kernel<64, 3>", "wino_input_kernel + wino_output_kernel + wino_fused_kernel + wino_mix_kernel",
              "conv3x3_halo_kernel", "conv_tall_kernel<256,64,4,1> / <128,32,4,1>", "conv_pw_kernel<96|64|32>",
-             "wino2_kernel<7|8> (fused F(2x2,3x3))"]
+             "wino2_kernel<4|2> (fused F(2x2,3x3))"]
 NTAGS = len(CFG_NAMES)
 
 

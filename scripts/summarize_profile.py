@@ -29,6 +29,7 @@ os.makedirs(dst, exist_ok=True)
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     m = re.match(r"(?:void )?(?:fh::)?(\w+)(<[^>]*>)?", name)
     if not m:
         return name[:60]
