@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256, 4) void front_kernel(const ConvArgs p, const i
         // 16 KB the A tile took are gone from LDS.  Accumulators start from the pointwise bias.  One MFMA per slot, the next
         // step's tap reads RA tap-slots ahead (ring registers), pinned by sched_barrier.
         {
-            const int pr_ = wid * 32 + fr, py = pr_ / DP_TW, pxx = pr_ - py * DP_TW;
+            const int pr_ = wid * 32 + fr, py = pr_ / DP_TW, pxx = (py & 1) ? (pr_ - py * DP_TW - 2) & (DP_TW - 1) : pr_ - py * DP_TW;   // (rotation: see dwpw_reg_kernel)
             const v4f* const hb = halo + (py * DP_HW + pxx) * 5 + fh2;
             const v4f* const db = cst + fh2;                                // [tap][4] + 2 j ; bias at tap 9
             v16f acc;
@@ -740,7 +740,11 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
     for (int i = tid; i < 32 * TN; i += 256) pwb[i] = i < Cout ? p.bias[i] : 0.f;
 
     // this lane's pixel and fragment addresses (float4 units)
-    const int pix = wid * 32 + r, py = pix / DP_TW, px = pix - py * DP_TW;
+    // (stride 1: the wave's second pixel row takes its columns rotated by 2.  A ds_read_b128 serves lanes {0-3, 12-15, 20-27} and
+    //  {4-11, 16-19, 28-31} together; with an odd pixel pitch the 16 addresses fall into 16 different bank quads iff the pixels' linear halo
+    //  indices differ mod 16, and a halo row is 18 = 16 + 2 pixels: unrotated, lanes 12 / 13 collide with lanes 26 / 27 and lanes 4 / 5 with
+    //  lanes 18 / 19 — every fragment read took 8 LDS cycles instead of 4 (SQ_LDS_BANK_CONFLICT = 27-34 % of SQ_LDS_IDX_ACTIVE, round-4 counters))
+    const int pix = wid * 32 + r, py = pix / DP_TW, px = DS == 1 && (py & 1) ? (pix - py * DP_TW - 2) & (DP_TW - 1) : pix - py * DP_TW;
     const v4f* const hbase = halo + (py * DS * HWD + px * DS) * PQ + h;    // + (ky * HWD + kx) * PQ + 2 j
     const v4f* const dbase = dwl + h;                                      // + tap * CQ + 2 j
     int wrow[TN];
