@@ -91,7 +91,7 @@ static long wino2_min_blocks() {                // workgroups per launch below w
     if (v < 0) {
         const char* e = getenv("FACEHIP_WINO2");
         const char* m = getenv("FACEHIP_WINO2_MIN");
-        v = e && atoi(e) == 0 ? (1L << 60) : m ? atol(m) : 256;
+        v = e && atoi(e) == 0 ? (1L << 60) : m ? atol(m) : 64;      // (measured, IResNet-50: fused form ahead from B = 8 on, level at B = 4)
     }
     return v;
 }
@@ -468,8 +468,8 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                     tag = 9;
                     break;
                 }
-                // fused F(2x2,3x3) for the few-channel 3x3 layers once there is at least one workgroup (2 tile groups of 4 x 7|8 tiles x 64
-                // channels) per CU; below that the direct kernel's split-K fills the chip better
+                // fused F(2x2,3x3) for the 64-channel 3x3 layers once there is about one one-wave workgroup per CU (wino2_blocks counts them
+                // in fours); below that the direct kernel's split-K fills the chip better
                 if (d.w2ok && winograd && force_cfg < 0 && d.sc_src < 0 && wino2_blocks(a) >= wino2_min_blocks()) {
                     a.wt = P + d.w2;
                     launch_wino2(a, s);
