@@ -800,6 +800,7 @@ int fh_conv_wino2_dev(const float* d_in, const float* w_ohwi, const float* d_bia
         return 0;
     });
 }
+double fh_debug_wino2_clock_mhz(void) { return fh::wino2_debug_clock_mhz(); }
 int fh_conv_wt_rows(int cout) { return fh::conv_wt_rows(cout); }
 int fh_conv_pack_weights(const float* w_ohwi, int cout, int cin, int ksize, float* dst_packed) {
     if (!w_ohwi || !dst_packed || cout <= 0 || cin <= 0) return arg_error("fh_conv_pack_weights: bad argument");

@@ -35,9 +35,11 @@
 // direct fp32 form (tests/test_gpu_round4.py bars single layers at 5e-5 abs on O(1) outputs; winograd.hip's F(4x4) needs 2e-4).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <vector>
 
 #include "kernels.h"
 #include "plan.h"
@@ -77,8 +79,11 @@ template <int V> struct IC { static constexpr int value = V; };          // comp
 template <int CB>
 __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const int tiles_n, const int tgx, const int tgy, const int n_tg) {
     extern __shared__ v4f w2sm[];
-    char* const halo = reinterpret_cast<char*>(w2sm);                      // [4 planes][5][5] pixels x 16 x 16 B
+    char* const halo = reinterpret_cast<char*>(w2sm);                      // [5][5] plane pixels x [4 parity planes] x 16 x 16 B
     const int lane = threadIdx.x;
+#ifdef FACEHIP_W2_PROF
+    const long long prof_c0 = __builtin_readcyclecounter(), prof_r0 = __builtin_amdgcn_s_memrealtime();   // shader clock vs the constant 100 MHz counter
+#endif
     int blk;
     {
         const int n = gridDim.x, q = n >> 3, r = n & 7, x = blockIdx.x & 7;
@@ -93,17 +98,19 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
     const int tn = lane & 15, kq = lane >> 4, tr = tn >> 2, tc = tn & 3;
     auto key = [](int pr, int pc) { return 2 * ((pc + 4 * (pr & 1)) & 7); };
 
-    // ---- halo: 25 pieces of 4 LDS rows (= pixels) x 16 columns; lane -> row 4 i + (lane >> 4), physical column lane & 15
+    // ---- halo: 25 pieces of 4 LDS rows x 16 columns.  LDS row 4 i + pl holds pixel i = 5 pr + pc of parity plane pl, so piece i is the same
+    // plane pixel of the four planes: its lanes' plane is lane >> 4 (computed once), its (pr, pc) and swizzle key are compile-time constants
+    // — ~10 VALU per piece instead of ~30 with plane-major rows (the bank a read hits does not depend on its row: a row is all 64 banks)
     {
-        const int col = lane & 15;
-        const float* const img = p.in + (size_t)gn * H * W * 64;
+        const int col = lane & 15, pl = lane >> 4;
+        const int y0 = 8 * gy - 1 + (pl >> 1), x0 = 8 * gx - 1 + (pl & 1);
+        const float* const img = p.in + ((size_t)gn * H * W + (size_t)y0 * W + x0) * 64;   // (may point in front of the image: only dereferenced when in range)
 #pragma unroll
         for (int i = 0; i < 25; ++i) {
-            const int R = 4 * i + (lane >> 4);
-            const int pl = R / 25, r2 = R - pl * 25, pr = r2 / 5, pc = r2 - pr * 5;
-            const int y = 8 * gy - 1 + 2 * pr + (pl >> 1), x = 8 * gx - 1 + 2 * pc + (pl & 1);
+            const int pr = i / 5, pc = i - 5 * pr;
+            const int y = y0 + 2 * pr, x = x0 + 2 * pc;
             const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            dma16(ok ? img + ((size_t)y * W + x) * 64 + ((col ^ key(pr, pc)) << 2) : p.zeros, halo + i * 1024);
+            dma16(ok ? img + ((long)2 * pr * W + 2 * pc) * 64 + ((col ^ key(pr, pc)) << 2) : p.zeros, halo + i * 1024);
         }
     }
     typedef const __attribute__((address_space(3))) v4f* lds_v4f;
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
 #pragma unroll
         for (int dx = 0; dx < 4; ++dx) {
             const int pl = (dy & 1) * 2 + (dx & 1), pr = tr + (dy >> 1), pc = tc + (dx >> 1);
-            rb[dy * 4 + dx] = halo_base + (unsigned)(((pl * 5 + pr) * 5 + pc) * 256 + ((key(pr, pc) ^ kq) << 4));
+            rb[dy * 4 + dx] = halo_base + (unsigned)((4 * (pr * 5 + pc) + pl) * 256 + ((key(pr, pc) ^ kq) << 4));
         }
     // weights of this column tile: step (f, j) = CB KB at ((f * 4 + j) * CB) * 256 floats; cb-th fragment + cb * 256
     // (a wave-uniform running pointer + the lane's 16-byte offset: with compile-time step offsets the 64 step addresses are hoisted out of
@@ -221,21 +228,27 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
     //  in front of the K loop and their ~80 destination registers are spilled through it)
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (abl_st && lane != 77) return;
+    if (abl_st && lane != 0) return;                                       // (lane 0 goes on to the clock stamp; 63 of 64 lanes' stores are gone)
     const int oy0 = 2 * (4 * gy + tr), ox0 = 2 * (4 * gx + tc);
     const int n0 = tile_n * 16 * CB, Cout = p.Cout;
     const float* __restrict__ res = p.res;
     float* __restrict__ out1 = p.out1;
     float* __restrict__ out2 = p.out2;
     const bool relu = p.act == (int)Act::RELU, prelu = p.act == (int)Act::PRELU;
+    float bm[CB][4];                                                       // CB = 2: this lane's 8 bias values, fetched once (no load between the stores)
+    if constexpr (CB == 2) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int co = n0 + 16 * cb + 4 * kq + e; bm[cb][e] = co < Cout ? p.bias[co] : 0.f; }
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int oy = oy0 + a, ox = ox0 + b;
-            if (oy >= p.Ho || ox >= p.Wo) continue;
-            const size_t pix = ((size_t)gn * p.Ho + oy) * p.Wo + ox;
-            const int cls = p.bias_cls ? 3 * (oy == 0 ? 0 : oy == p.Ho - 1 ? 2 : 1) + (ox == 0 ? 0 : ox == p.Wo - 1 ? 2 : 1) : 0;
+            if (CB != 2 || oy >= p.Ho || ox >= p.Wo) continue;
+            const size_t pix = ((size_t)gn * p.Ho + oy) * p.Wo + ox;       // (merged convolutions carry no folded BatchNorm: wino2_ok)
             if constexpr (CB == 2) {                                       // merged sibling convolutions (the only CB = 2 users): per-channel-range destination and activation
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
@@ -245,20 +258,17 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
                         if (co >= Cout) continue;
                         const int g = co >= p.oc0[2] && p.n_outs > 2 ? 2 : co >= p.oc0[1] ? 1 : 0;
                         const int cg = p.oc0[g + 1] - p.oc0[g], ga = p.oact[g];
-                        auto fin = [&](float v, int c) {
-                            v += p.bias[cls * Cout + c];
-                            return ga == (int)Act::RELU ? fmaxf(v, 0.f) : ga == (int)Act::SIGMOID ? 1.0f / (1.0f + expf(-v)) : v;
-                        };
+                        auto fin = [&](float v) { return ga == (int)Act::RELU ? fmaxf(v, 0.f) : ga == (int)Act::SIGMOID ? 1.0f / (1.0f + expf(-v)) : v; };
                         float* const dst = p.outs[g] + pix * cg + (co - p.oc0[g]);
-                        const float v0 = fin(Y[a][b][cb][e], co);
+                        const float v0 = fin(Y[a][b][cb][e] + bm[cb][e]);
                         if (co + 1 < p.oc0[g + 1] && !((cg | (co - p.oc0[g])) & 1)) {
-                            *reinterpret_cast<float2*>(dst) = float2{v0, fin(Y[a][b][cb][e + 1], co + 1)};
+                            *reinterpret_cast<float2*>(dst) = float2{v0, fin(Y[a][b][cb][e + 1] + bm[cb][e + 1])};
                         } else {
                             dst[0] = v0;
                             if (co + 1 < Cout) {                          // the pair straddles two destinations (or is unaligned): scalar stores
                                 const int g1 = co + 1 >= p.oc0[2] && p.n_outs > 2 ? 2 : co + 1 >= p.oc0[1] ? 1 : 0;
                                 const int cg1 = p.oc0[g1 + 1] - p.oc0[g1], ga1 = p.oact[g1];
-                                float v1 = Y[a][b][cb][e + 1] + p.bias[cls * Cout + co + 1];
+                                float v1 = Y[a][b][cb][e + 1] + bm[cb][e + 1];
                                 v1 = ga1 == (int)Act::RELU ? fmaxf(v1, 0.f) : ga1 == (int)Act::SIGMOID ? 1.0f / (1.0f + expf(-v1)) : v1;
                                 p.outs[g1][pix * cg1 + (co + 1 - p.oc0[g1])] = v1;
                             }
@@ -266,29 +276,51 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
                     }
                 continue;
             }
-            if constexpr (CB == 2) continue;                               // (the vector epilogue below is the CB = 4 form's)
-            const size_t row = pix * Cout + n0 + 4 * kq;
-            v4f r4[CB];
-            if (p.res_mode != (int)ResMode::NONE) {
+        }
+    if constexpr (CB == 4) {
+        // Every load of the epilogue goes out BEFORE the first store: bias per pixel (its border class), slope, residual — 36 float4 per lane
+        // in flight together, ONE global-memory latency.  (Per pixel "load, wait, compute, store" was four latencies in a row: with the
+        // stores masked to one lane of 64 the epilogue still cost 33 of the layer's 195 us — it was never the traffic.)
+        const int n0 = tile_n * 16 * CB + 4 * kq;
+        bool live[4]; size_t row[4]; v4f b4[4][CB], r4[4][CB], sl[CB];
 #pragma unroll
-                for (int cb = 0; cb < CB; ++cb) r4[cb] = *reinterpret_cast<const v4f*>(res + row + 16 * cb);
-            }
+        for (int cb = 0; cb < CB; ++cb) sl[cb] = prelu ? *reinterpret_cast<const v4f*>(p.slope + n0 + 16 * cb) : v4f{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oy = oy0 + (q >> 1), ox = ox0 + (q & 1);
+            live[q] = oy < p.Ho && ox < p.Wo;
+            const int oyc = min(oy, p.Ho - 1), oxc = min(ox, p.Wo - 1);     // (clamped: dead pixels load a neighbour's vectors and store nothing)
+            row[q] = (((size_t)gn * p.Ho + oyc) * p.Wo + oxc) * Cout + n0;
+            const int cls = p.bias_cls ? 3 * (oyc == 0 ? 0 : oyc == p.Ho - 1 ? 2 : 1) + (oxc == 0 ? 0 : oxc == p.Wo - 1 ? 2 : 1) : 0;
 #pragma unroll
             for (int cb = 0; cb < CB; ++cb) {
-                const int co = n0 + 16 * cb + 4 * kq;
-                const v4f b4 = p.bias ? *reinterpret_cast<const v4f*>(p.bias + cls * Cout + co) : v4f{0.f, 0.f, 0.f, 0.f};
-                const v4f sl = prelu ? *reinterpret_cast<const v4f*>(p.slope + co) : v4f{1.f, 1.f, 1.f, 1.f};
+                b4[q][cb] = p.bias ? *reinterpret_cast<const v4f*>(p.bias + cls * Cout + n0 + 16 * cb) : v4f{0.f, 0.f, 0.f, 0.f};
+                if (p.res_mode != (int)ResMode::NONE) r4[q][cb] = *reinterpret_cast<const v4f*>(res + row[q] + 16 * cb);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!live[q]) continue;
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
                 v4f v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = act1(Y[a][b][cb][e] + b4[e], relu, sl[e]);
-                if (p.res_mode != (int)ResMode::NONE) v += r4[cb];
-                if (out1) *reinterpret_cast<v4f*>(out1 + row + 16 * cb) = v;
+                for (int e = 0; e < 4; ++e) v[e] = act1(Y[q >> 1][q & 1][cb][e] + b4[q][cb][e], relu, sl[cb][e]);
+                if (p.res_mode != (int)ResMode::NONE) v += r4[q][cb];
+                if (out1) *reinterpret_cast<v4f*>(out1 + row[q] + 16 * cb) = v;
                 if (out2) {
-                    const v4f s2 = *reinterpret_cast<const v4f*>(p.s2 + co), t2 = *reinterpret_cast<const v4f*>(p.t2 + co);
-                    *reinterpret_cast<v4f*>(out2 + row + 16 * cb) = v * s2 + t2;
+                    const v4f s2 = *reinterpret_cast<const v4f*>(p.s2 + n0 + 16 * cb), t2 = *reinterpret_cast<const v4f*>(p.t2 + n0 + 16 * cb);
+                    *reinterpret_cast<v4f*>(out2 + row[q] + 16 * cb) = v * s2 + t2;
                 }
             }
         }
+    }
+#ifdef FACEHIP_W2_PROF
+    if (lane == 0 && p.slabs && blockIdx.x < (1u << 17)) {                 // this wave's mean shader clock in MHz x 10 -> the diagnostic buffer (never an output)
+        const long long dc = __builtin_readcyclecounter() - prof_c0, dr = (long long)__builtin_amdgcn_s_memrealtime() - prof_r0;
+        reinterpret_cast<float*>(p.slabs)[blockIdx.x] = (float)(dc * 1000 / (dr + 1));
+    }
+#endif
 }
 
 bool shape_ok(int Cin, int Cout) { return Cin == 64 && (Cout % 64 == 0 || Cout <= 32); }   // (<= 32: merged outputs only, see wino2_ok)
@@ -343,6 +375,20 @@ bool wino2_ok(const ConvArgs& a) {
     return a.Cout % 64 == 0;                                               // plain layers: whole 64-channel column tiles
 }
 
+// diagnostic runs (FACEHIP_W2_ABLATE set, diagnostic build): per-workgroup shader-clock stamps land in a 512 KB device buffer; returns their
+// median in MHz (0 in production builds, which never write it)
+static float* g_w2_clock = nullptr;
+double wino2_debug_clock_mhz() {
+    if (!g_w2_clock) return 0.0;
+    std::vector<float> h(1 << 17);
+    if (hipMemcpy(h.data(), g_w2_clock, h.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return 0.0;
+    std::vector<float> v;
+    for (float x : h) if (x > 0.f) v.push_back(x);
+    if (v.empty()) return 0.0;
+    std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+    return v[v.size() / 2] / 10.0;
+}
+
 // one-wave workgroups of the launch, in units of four (= the 256-thread workgroups the engine's cross-over is expressed in)
 long wino2_blocks(const ConvArgs& a) {
     return (long)a.B * (((a.H + 1) / 2 + 3) / 4) * (((a.W + 1) / 2 + 3) / 4) * ((a.Cout + 63) / 64) / 4;
@@ -353,7 +399,11 @@ void launch_wino2(const ConvArgs& a_in, hipStream_t s) {
     if (!wino2_ok(a_in)) throw std::runtime_error("launch_wino2: layer shape not supported");
     ConvArgs a = a_in;
     a.zeros = conv_zero_line();
-    { const char* e = getenv("FACEHIP_W2_ABLATE"); a.sk_test_drop = e ? atoi(e) : 0; }   // (read by diagnostic builds only: scripts/wino2_prof.sh)
+    static const int ablate = [] { const char* e = getenv("FACEHIP_W2_ABLATE"); return e ? atoi(e) : -1; }();
+    a.sk_test_drop = ablate < 0 ? 0 : ablate;                              // (read by diagnostic builds only: scripts/wino2_prof.sh)
+    if (ablate >= 0 && !g_w2_clock) { void* q = nullptr; if (hipMalloc(&q, sizeof(float) << 17) == hipSuccess) g_w2_clock = (float*)q; }
+    if (g_w2_clock) (void)hipMemsetAsync(g_w2_clock, 0, sizeof(float) << 17, s);
+    a.slabs = g_w2_clock;
     if (a.Cout <= 32) launch_cb<2>(a, s);
     else launch_cb<4>(a, s);
 }

@@ -121,6 +121,7 @@ void wino2_pack_weights(const float* w_ohwi, int Cout, int Cin, float* dst);
 bool wino2_ok(const ConvArgs& a);
 void launch_wino2(const ConvArgs& a, hipStream_t s);
 long wino2_blocks(const ConvArgs& a);          // workgroups the launch would have
+double wino2_debug_clock_mhz();                // diagnostic builds (scripts/wino2_prof.sh): median in-kernel shader clock of the last launch
 const float* conv_zero_line();                // 8 KiB of device zeros (target of padded / dead loads)
 int conv_num_cus();                           // compute units of the current device
 // dense 3x3 stride-1 convolutions with 16 input channels and <= 64 output channels on an 8x16 spatial tile with an LDS halo

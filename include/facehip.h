@@ -246,6 +246,9 @@ FH_API int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi_host, con
  * act = 0 none / 1 ReLU / 2 PReLU (d_slope [cout]) ...; d_res = optional residual of the output's shape.  Synchronous. */
 FH_API int fh_conv_wino2_dev(const float* d_in, const float* w_ohwi_host, const float* d_bias, const float* d_slope, const float* d_res,
                              float* d_out, int batch, int h, int w, int cin, int cout, int act, int bias_cls, void* stream);
+/* Diagnostic builds of conv_wino2.hip (-DFACEHIP_W2_PROF, scripts/wino2_prof.sh, FACEHIP_W2_ABLATE set): median shader clock in MHz the
+ * waves of the last wino2 launch measured (s_memtime against the 100 MHz s_memrealtime).  0 in production builds. */
+FH_API double fh_debug_wino2_clock_mhz(void);
 /* Batch-1 host-pointer calls (fh_det_detect, fh_rec_extract, fh_rec_extract_simple — the reference's own mode, src/main.cpp:88-104) are
  * captured into a HIP graph per call shape (image size / pitch, thresholds) and replayed: first call with a shape eager, second
  * captured, later ones one hipGraphLaunch each.  Results are bitwise those of the eager path.  fh_set_graph_replay(0) (or

@@ -19,7 +19,7 @@ def key(pr, pc):
 
 def lds_row(tr, tc, dy, dx):
     pl, pr, pc = (dy & 1) * 2 + (dx & 1), tr + (dy >> 1), tc + (dx >> 1)
-    return (pl * 5 + pr) * 5 + pc, pr, pc
+    return 4 * (pr * 5 + pc) + pl, pr, pc                            # LDS row: the four parity planes interleaved
 
 
 def bank_report():
@@ -61,8 +61,8 @@ def emulate(B, H, W, Cout, seed=0):
     for tg in range(B * tgy * tgx):
         gn, rem = divmod(tg, tgy * tgx); gy, gx = divmod(rem, tgx)
         halo = np.zeros((100, 16, 4))
-        for R in range(100):                                        # the 25 DMA pieces
-            pl, r2 = divmod(R, 25); pr, pc = divmod(r2, 5)
+        for R in range(100):                                        # the 25 DMA pieces: piece i = plane pixel i of the four planes
+            r2, pl = divmod(R, 4); pr, pc = divmod(r2, 5)
             y, xx = 8 * gy - 1 + 2 * pr + (pl >> 1), 8 * gx - 1 + 2 * pc + (pl & 1)
             if 0 <= y < H and 0 <= xx < W:
                 for col in range(16):

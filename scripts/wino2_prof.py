@@ -17,4 +17,5 @@ for _ in range(4):
 torch.cuda.synchronize()
 cap = 100; ms = (C.c_double * cap)(); fl = (C.c_double * cap)(); tg = (C.c_int * cap)()
 nrec = L.fh_timing_collect_ops(ms, fl, tg, cap)
-print("kernel time:", [round(ms[i] * 1e3, 1) for i in range(nrec) if tg[i] == 12][1:], "us")
+print("kernel time:", [round(ms[i] * 1e3, 1) for i in range(nrec) if tg[i] == 12][1:], "us;  in-kernel shader clock (median over the waves of the last launch):",
+      round(L.fh_debug_wino2_clock_mhz()), "MHz")
