@@ -103,6 +103,8 @@ PROTOTYPES = {
     "fh_det_set_conv_cfg": (_i, [_vp, _i, _i]),
     "fh_rec_set_conv_cfg": (_i, [_vp, _i, _i]),
     "fh_memcpy_d2h": (_i, [_vp, _vp, C.c_size_t]),
+    "fh_det_sync": (_i, [_vp, _vp]),
+    "fh_rec_sync": (_i, [_vp, _vp]),
     "fh_imread": (_i, [C.c_char_p, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)]),
     "fh_image_decode": (_i, [_vp, C.c_size_t, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i)]),
     "fh_image_free": (None, [_vp]),

@@ -115,6 +115,10 @@ class FaceDetector:
                                                         scoreThreshold, nmsThreshold, out_ptr, max_per_frame,
                                                         counts_ptr, stream), "fh_det_detect_batch_dev")
 
+    def sync(self, stream: int = 0) -> None:
+        """Waits for `stream`; raises if a launch of this handle failed after its asynchronous call returned (fh_det_sync)."""
+        check(_lib.lib().fh_det_sync(self._h, stream), "fh_det_sync")
+
 
 class FaceRecognizer:
     def __init__(self):
@@ -197,6 +201,10 @@ class FaceRecognizer:
     def embed_aligned_dev(self, crops_ptr: int, n: int, out_ptr: int, raw_ptr: int = 0, stream: int = 0) -> int:
         return check(_lib.lib().fh_rec_embed_aligned_dev(self._h, crops_ptr, n, out_ptr, raw_ptr, stream),
                      "fh_rec_embed_aligned_dev")
+
+    def sync(self, stream: int = 0) -> None:
+        """Waits for `stream`; raises if a launch of this handle failed after its asynchronous call returned (fh_rec_sync)."""
+        check(_lib.lib().fh_rec_sync(self._h, stream), "fh_rec_sync")
 
 
 def pipeline_run_dev(det: FaceDetector, rec: FaceRecognizer, frames_ptr: int, n: int, rows: int, cols: int,

@@ -14,13 +14,26 @@ static_assert(sizeof(fh_face) == 60 && sizeof(fh::FaceRec) == 60, "FaceBox mirro
 namespace {
 thread_local std::string g_err;
 
+// Which handles the running API call works on (set by the entry point before guarded(), cleared when it returns).  Each Net owns its
+// stream-K watchdog record, so a hand-off time-out is reported by a call on the handle whose launch was abandoned: a call on another
+// handle, or on none, neither sees nor consumes it.  (The single-kernel test entry points share the process-wide record: `shared`.)
+struct CallOwners { const fh::Net* net[2] = {nullptr, nullptr}; bool shared = false; };
+thread_local CallOwners t_owners;
+struct Owns {
+    explicit Owns(const fh::Net* a, const fh::Net* b = nullptr) { t_owners.net[0] = a; t_owners.net[1] = b; t_owners.shared = !a && !b; }
+    ~Owns() { t_owners = CallOwners{}; }
+    Owns(const Owns&) = delete;
+    Owns& operator=(const Owns&) = delete;
+};
 template <class F>
 int guarded(F&& f) {
     try {
         const int rc = f();
-        // stream-K watchdog (conv_mfma.hip): a launch whose hand-off timed out has reported through the host-mapped record by the
-        // time any later call gets here (the synchronous entry points: in this very call, after their own stream sync)
-        if (fh::conv_take_error(g_err)) return FH_ERR_DEVICE;
+        // stream-K watchdog (conv_mfma.hip): a launch whose hand-off timed out has reported through its Net's host-mapped record by the
+        // time a later call on that handle gets here (the synchronous entry points: in this very call, after their own stream sync)
+        for (const fh::Net* n : t_owners.net)
+            if (n && fh::conv_take_error(g_err, n->error_record())) return FH_ERR_DEVICE;
+        if (t_owners.shared && fh::conv_take_error(g_err, fh::conv_error_words())) return FH_ERR_DEVICE;
         return rc;
     } catch (const std::exception& e) {
         g_err = e.what();
@@ -231,6 +244,7 @@ int fh_det_detect_batch_dev(fh_det* d, const uint8_t* frames, int n, int rows, i
                             float score_thr, float nms_thr, fh_face* out, int max_pf, int* counts, void* stream) {
     if (!d || !frames || !out || !counts) return arg_error("fh_det_detect_batch_dev: null argument");
     if (n <= 0 || rows <= 0 || cols <= 0 || step < cols * 3 || max_pf <= 0) return arg_error("fh_det_detect_batch_dev: bad size");
+    Owns owns(&d->det.net());
     return guarded([&] {
         d->det.detect_dev(frames, n, rows, cols, step, (long)stride, score_thr, nms_thr, reinterpret_cast<fh::FaceRec*>(out), max_pf,
                           counts, S(stream));
@@ -243,6 +257,7 @@ int fh_det_detect(fh_det* d, const uint8_t* bgr, int rows, int cols, int step, f
     if (!d) return arg_error("Model not loaded!");                       // src/face_detector.cpp:142-145
     if (!bgr || rows <= 0 || cols <= 0) return 0;                        // :148-156 -> empty result
     if (!out || max_out <= 0 || step < cols * 3) return arg_error("fh_det_detect: bad output buffer / step");
+    Owns owns(&d->det.net());
     return guarded([&] {
         const size_t bytes = (size_t)rows * step, used = host_image_bytes(rows, cols, step);
         const int in_graph = max_out < kGraphFaces ? max_out : kGraphFaces;
@@ -283,8 +298,14 @@ int fh_det_detect(fh_det* d, const uint8_t* bgr, int rows, int cols, int step, f
     });
 }
 
+int fh_det_sync(fh_det* d, void* stream) {
+    if (!d) return arg_error("fh_det_sync: null handle");
+    Owns owns(&d->det.net());
+    return guarded([&] { FH_HIP(hipStreamSynchronize(S(stream))); return (int)FH_OK; });
+}
 int fh_det_run_network_dev(fh_det* d, const uint8_t* frames, int n, int rows, int cols, int step, long long stride, void* stream) {
     if (!d || !frames || n <= 0) return arg_error("fh_det_run_network_dev: bad argument");
+    Owns owns(&d->det.net());
     return guarded([&] { d->det.run_network_dev(frames, n, rows, cols, step, (long)stride, S(stream)); return n; });
 }
 int fh_det_num_outputs(const fh_det* d) { return d ? (int)const_cast<fh_det*>(d)->det.net().plan().outputs.size() : arg_error("null handle"); }
@@ -298,6 +319,7 @@ const float* fh_det_output_dev(fh_det* d, int index, int* rows, int* cols) {
 const float* fh_det_input_dev(fh_det* d) { return d && d->det.net().capacity() > 0 ? d->det.net().input() : nullptr; }
 int fh_det_postprocess_dev(fh_det* d, int n, float score_thr, float nms_thr, fh_face* out, int max_pf, int* counts, void* stream) {
     if (!d || !out || !counts || n <= 0) return arg_error("fh_det_postprocess_dev: bad argument");
+    Owns owns(&d->det.net());
     return guarded([&] { d->det.postprocess_dev(n, score_thr, nms_thr, reinterpret_cast<fh::FaceRec*>(out), max_pf, counts, S(stream)); return n; });
 }
 
@@ -371,11 +393,18 @@ const float* fh_rec_input_dev(fh_rec* r) { return r && r->rec.net().capacity() >
 
 int fh_rec_embed_aligned_dev(fh_rec* r, const uint8_t* crops, int n, float* out, float* raw, void* stream) {
     if (!r || !crops || !out || n <= 0) return arg_error("fh_rec_embed_aligned_dev: bad argument");
+    Owns owns(&r->rec.net());
     return guarded([&] { r->rec.embed_aligned_dev(crops, n, out, S(stream), raw); return n; });
+}
+int fh_rec_sync(fh_rec* r, void* stream) {
+    if (!r) return arg_error("fh_rec_sync: null handle");
+    Owns owns(&r->rec.net());
+    return guarded([&] { FH_HIP(hipStreamSynchronize(S(stream))); return (int)FH_OK; });
 }
 int fh_rec_align_dev(fh_rec* r, const uint8_t* frames, int rows, int cols, int step, long long stride, const fh_face* faces,
                      const int* frame_of, int n, uint8_t* crops, int* ok, void* stream) {
     if (!r || !frames || !faces || !crops || !ok || n <= 0 || rows <= 0 || cols <= 0) return arg_error("fh_rec_align_dev: bad argument");
+    Owns owns(&r->rec.net());
     return guarded([&] {
         r->rec.align_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, n, crops, ok, S(stream));
         return n;
@@ -384,6 +413,7 @@ int fh_rec_align_dev(fh_rec* r, const uint8_t* frames, int rows, int cols, int s
 int fh_rec_embed_faces_dev(fh_rec* r, const uint8_t* frames, int rows, int cols, int step, long long stride, const fh_face* faces,
                            const int* frame_of, int n, float* out, int* ok, void* stream) {
     if (!r || !frames || !faces || !out || n <= 0 || rows <= 0 || cols <= 0) return arg_error("fh_rec_embed_faces_dev: bad argument");
+    Owns owns(&r->rec.net());
     return guarded([&] {
         r->rec.embed_faces_dev(frames, rows, cols, step, (long)stride, reinterpret_cast<const fh::FaceRec*>(faces), frame_of, n, out, ok, S(stream));
         return n;
@@ -395,6 +425,7 @@ int fh_rec_extract(fh_rec* r, const uint8_t* bgr, int rows, int cols, int step, 
     if (!bgr || rows <= 0 || cols <= 0) return 0;                         // :245-248 -> empty vector
     if (!face || !out || step < cols * 3) return arg_error("fh_rec_extract: bad argument");
     if (out_cap < r->rec.dim()) return arg_error("fh_rec_extract: output buffer too small");
+    Owns owns(&r->rec.net());
     return guarded([&] {
         const size_t bytes = (size_t)rows * step, used = host_image_bytes(rows, cols, step);
         const size_t dimb = (size_t)r->rec.dim() * sizeof(float);
@@ -430,6 +461,7 @@ int fh_rec_extract_simple(fh_rec* r, const uint8_t* bgr, int rows, int cols, int
     if (!bgr || rows <= 0 || cols <= 0) return 0;
     if (!out || step < cols * 3) return arg_error("fh_rec_extract_simple: bad argument");
     if (out_cap < r->rec.dim()) return arg_error("fh_rec_extract_simple: output buffer too small");
+    Owns owns(&r->rec.net());
     return guarded([&] {
         const size_t bytes = (size_t)rows * step, used = host_image_bytes(rows, cols, step);
         const size_t dimb = (size_t)r->rec.dim() * sizeof(float);
@@ -488,6 +520,7 @@ int fh_pipeline_run_dev(fh_det* d, fh_rec* r, const uint8_t* frames, int n, int 
                         float score_thr, float nms_thr, int F, fh_face* faces, int* frame_of, float* emb, void* stream) {
     if (!d || !r || !frames || !faces || !frame_of || !emb) return arg_error("fh_pipeline_run_dev: null argument");
     if (n <= 0 || n > 4096 || rows <= 0 || cols <= 0 || F <= 0) return arg_error("fh_pipeline_run_dev: bad size");
+    Owns owns(&d->det.net(), &r->rec.net());
     return guarded([&] {
         hipStream_t s = S(stream);
         const int total = detect_select_count(d, frames, n, rows, cols, step, (long)stride, score_thr, nms_thr, F, faces, frame_of, nullptr, s);
@@ -504,6 +537,7 @@ int fh_pipeline_submit_dev(fh_det* d, fh_rec* r, const uint8_t* frames, int n, i
                            void* stream_det, void* stream_rec) {
     if (!d || !r || !frames || !faces || !frame_of || !emb || !d_total) return arg_error("fh_pipeline_submit_dev: null argument");
     if (n <= 0 || n > 4096 || rows <= 0 || cols <= 0 || F <= 0) return arg_error("fh_pipeline_submit_dev: bad size");
+    Owns owns(&d->det.net(), &r->rec.net());
     return guarded([&] {
         hipStream_t sd = S(stream_det), sr = S(stream_rec);
         const int total = detect_select_count(d, frames, n, rows, cols, step, (long)stride, score_thr, nms_thr, F, faces, frame_of, d_total, sd);
@@ -567,6 +601,7 @@ int fh_stream_submit(fh_stream* st, const uint8_t* host_frames, int n_frames, fl
     if (!st || !host_frames) return arg_error("fh_stream_submit: null argument");
     if (n_frames <= 0 || n_frames > st->n) return arg_error("fh_stream_submit: batch larger than the stream was created for");
     if (st->submitted - st->collected >= fh_stream::kSlots) { g_err = "fh_stream_submit: ring full, collect a batch first"; return FH_ERR_STATE; }
+    Owns owns(&st->det->det.net(), &st->rec->rec.net());
     return guarded([&] {
         fh_stream::Slot& sl = st->slot[st->submitted % fh_stream::kSlots];
         // upload on the copy stream (overlaps the batch computing on comp_s), compute behind the upload's event
@@ -588,6 +623,7 @@ int fh_stream_submit(fh_stream* st, const uint8_t* host_frames, int n_frames, fl
 int fh_stream_collect(fh_stream* st, fh_face* faces, int* frame_of, float* emb, int cap) {
     if (!st) return arg_error("fh_stream_collect: null handle");
     if (st->collected >= st->submitted) { g_err = "fh_stream_collect: nothing in flight"; return FH_ERR_STATE; }
+    Owns owns(&st->det->det.net(), &st->rec->rec.net());
     return guarded([&] {
         fh_stream::Slot& sl = st->slot[st->collected % fh_stream::kSlots];
         FH_HIP(hipEventSynchronize(sl.done));
@@ -663,6 +699,7 @@ int fh_rec_set_wino_fusion(fh_rec* r, int on) { if (!r) return arg_error("null h
 int fh_rec_set_precision(fh_rec* r, int mode, float* worst_out) {
     if (!r || (mode != FH_PREC_FP32 && mode != FH_PREC_BF16X2)) return arg_error("fh_rec_set_precision: bad argument");
     if (worst_out) *worst_out = 0.f;
+    Owns owns(&r->rec.net());
     if (mode == FH_PREC_FP32) return guarded([&] { r->rec.net().set_bf16x2(false, nullptr); return (int)FH_OK; });
     return guarded([&] {
         fh::Net& net = r->rec.net();
@@ -745,6 +782,7 @@ int fh_resize_u8c3_dev(const uint8_t* src, int sh, int sw, int sstep, uint8_t* d
 int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi, const float* d_bias, float* d_out, int batch, int h, int w, int cin,
                          int cout, void* stream) {
     if (!d_in || !w_ohwi || !d_out || cin % 32 || cout % 4) return arg_error("fh_conv_winograd_dev: bad argument");
+    Owns owns(nullptr);                                                  // (no Net: the process-wide watchdog record)
     return guarded([&] {
         const int rows = fh::conv_wt_rows(cout);
         std::vector<float> u36((size_t)36 * rows * cin, 0.f), uf((size_t)cout * cin);
@@ -825,6 +863,7 @@ int fh_debug_streamk(int drop_publish, int timeout_ms) { fh::conv_debug_streamk(
 int fh_conv_forward_dev(const float* in, const float* wt, const float* bias, float* out, int batch, int h, int w, int cin, int cout,
                         int ks, int stride, int kpad, int cfg, void* stream) {
     if (!in || !wt || !out || batch <= 0 || (ks != 1 && ks != 3) || cin % 4) return arg_error("fh_conv_forward_dev: bad argument");
+    Owns owns(nullptr);                                                  // (no Net: the process-wide watchdog record)
     return guarded([&] {
         fh::ConvArgs a{};
         const int pad = ks / 2;

@@ -41,7 +41,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
+#include <vector>
 
 #include "kernels.h"
 #include "plan.h"
@@ -521,9 +523,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
             if (tid == 0) {                                 // ONE lane polls relaxed, then ONE acquire
                 // Bounded wait: forward progress rests on helpers (lower block indices) being dispatched before owners, which HIP
                 // does not promise.  Past sk_timeout (default 2 s of the constant 100 MHz clock — five orders of magnitude beyond any
-                // real wait) the owner gives up: it reports (tile, arrivals seen, arrivals expected) through the host-visible error
-                // record, leaves its tile unwritten and exits, so that the launch drains and the NEXT fh_* call returns
-                // FH_ERR_DEVICE instead of the process hanging with the GPU lease.
+                // real wait) the owner gives up: it reports (tile, arrivals seen, arrivals expected) through its Net's host-visible
+                // error record, leaves its tile unwritten and exits, so that the launch drains and the next call on that handle
+                // returns FH_ERR_DEVICE instead of the process hanging with the GPU lease.
                 const unsigned long long t0 = wall_clock64();
                 unsigned seen, spins = 0;
                 bool arrived = true;
@@ -965,8 +967,32 @@ unsigned* conv_error_words() {
     }
     return g_sk_err;
 }
-bool conv_take_error(std::string& msg) {
-    volatile unsigned* e = g_sk_err;
+// One record per Net (allocated with its workspace) so that a time-out is reported by a call on the handle whose launch was abandoned;
+// launches without one (the single-kernel test entry points) share the process-wide record above.  Records are never freed while the
+// device may still write them: a Net parks its record on a free list at destruction.
+static std::vector<unsigned*> g_sk_free;
+static std::mutex g_sk_mu;
+unsigned* conv_error_record_new() {
+    {
+        std::lock_guard<std::mutex> lk(g_sk_mu);
+        if (!g_sk_free.empty()) { unsigned* r = g_sk_free.back(); g_sk_free.pop_back(); memset(r, 0, 64); return r; }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+    memset(p, 0, 64);
+    return (unsigned*)p;
+}
+void conv_error_record_release(unsigned* r) {
+    if (!r) return;
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    g_sk_free.push_back(r);
+}
+bool conv_error_pending(const unsigned* rec) {
+    const volatile unsigned* e = rec;
+    return e && e[0];
+}
+bool conv_take_error(std::string& msg, unsigned* rec) {
+    volatile unsigned* e = rec;
     if (!e || !e[0]) return false;
     char buf[256];
     snprintf(buf, sizeof buf, "HIP error: stream-K hand-off timed out (remainder tile %u saw %u of %u helper arrivals): the launch was "
@@ -1113,7 +1139,7 @@ static void launch_cfg_tail(ConvArgs a, int resident_per_cu, int cfg_tag, hipStr
     }
     if (!helpers) { full = T; R = 0; }
     a.sk_full = full; a.sk_helpers = helpers; a.sk_rem = R;
-    a.sk_err = owners ? conv_error_words() : nullptr; a.sk_timeout = g_sk_timeout; a.sk_test_drop = g_sk_test_drop;
+    a.sk_err = owners ? (a.sk_err ? a.sk_err : conv_error_words()) : nullptr; a.sk_timeout = g_sk_timeout; a.sk_test_drop = g_sk_test_drop;
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
     const dim3 grid((unsigned)(full + helpers + owners));

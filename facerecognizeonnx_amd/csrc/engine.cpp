@@ -326,6 +326,8 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
     for (auto& op : plan_.ops) { std::vector<float>().swap(op.weight); }
 }
 
+Net::SkRecord::~SkRecord() { conv_error_record_release(p); }
+
 void Net::reserve(int max_batch) {
     if (max_batch <= cap_) return;
     cap_ = max_batch;
@@ -333,6 +335,8 @@ void Net::reserve(int max_batch) {
     if (partial_.bytes < conv_slab_floats() * sizeof(float)) {
         partial_.ensure(conv_slab_floats() * sizeof(float));
         conv_workspace_init(partial_.as<float>());
+        if (!sk_rec_.p) sk_rec_.p = conv_error_record_new();
+        if (!sk_rec_.p) throw std::runtime_error("HIP error: cannot allocate the stream-K watchdog record");
         sk_gen_ = conv_error_generation();
     }
     if (wino_elems_) {
@@ -406,7 +410,7 @@ int Net::set_bf16x2(bool on, hipStream_t s) {
 
 void Net::run(int batch, hipStream_t s, int first_op) {
     if (batch <= 0) return;
-    if (sk_gen_ != conv_error_generation() && partial_.p) {   // a stream-K hand-off timed out somewhere since: late helper arrivals may have
+    if ((sk_gen_ != conv_error_generation() || conv_error_pending(sk_rec_.p)) && partial_.p) {   // a stream-K hand-off timed out somewhere since: late helper arrivals may have
         conv_workspace_reset_async(partial_.as<float>(), s);  // left counters non-zero — re-zero them, stream-ordered, before the next launch
         sk_gen_ = conv_error_generation();
     }
@@ -441,6 +445,7 @@ void Net::run(int batch, hipStream_t s, int first_op) {
                 a.s2 = d.has_aff ? P + d.s2 : nullptr;
                 a.t2 = d.has_aff ? P + d.t2 : nullptr;
                 a.slabs = partial_.as<float>();
+                a.sk_err = sk_rec_.p;
                 a.sk_enable = sk_enable ? 1 : 0;
                 a.cus = cus;
                 a.no_pw = force_cfg >= 0 ? 1 : 0;

@@ -97,6 +97,7 @@ class Net {
     };
   public:
     float* workspace() const { return partial_.as<float>(); }   // stream-K slabs (diagnostic builds of dwpw_mfma.hip park phase stamps there)
+    unsigned* error_record() const { return sk_rec_.p; }        // this Net's stream-K watchdog record (null before reserve)
   private:
     float* tensor_ptr(int t) const { return arena_.as<float>() + plan_.tensors[t].offset * (size_t)cap_; }
     Plan plan_;
@@ -106,6 +107,13 @@ class Net {
     size_t wino_maxc_ = 0;
     size_t wino_elems_ = 0;                                   // per image: 36 * tiles * max(Cin, Cout) of the largest Winograd op
     int cap_ = 0;
+    struct SkRecord {                                         // host-mapped; parked on a free list at destruction (the device may still write it)
+        unsigned* p = nullptr;
+        SkRecord() = default;
+        SkRecord(const SkRecord&) = delete;
+        SkRecord& operator=(const SkRecord&) = delete;
+        ~SkRecord();
+    } sk_rec_;
     unsigned sk_gen_ = 0;                                     // conv_error_generation() this Net's hand-off counters were last zeroed under
     bool stem_ok_ = false;
     bool front_ok_ = false;                                   // ops 0 + 1 = stem conv (16 channels) -> DW+PW: one kernel

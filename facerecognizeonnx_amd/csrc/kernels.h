@@ -106,11 +106,15 @@ int conv_pick_cfg(long M, int Cout);
 void conv_workspace_init(float* ws);          // zero the counter words of a freshly allocated stream-K workspace
 void conv_workspace_reset_async(float* ws, hipStream_t s);   // the same, stream-ordered (after a reported hand-off time-out)
 // Stream-K watchdog.  An owner workgroup whose helpers never arrive gives up after a bounded wait and reports through a host-mapped
-// record; conv_take_error() returns true once (with a message starting "HIP error") and bumps conv_error_generation(), after which
+// record of the launching Net's own; conv_take_error(msg, rec) — called with the records of the handles an API call works on — returns
+// true once for that handle (with a message starting "HIP error") and bumps conv_error_generation(), after which
 // every Net re-zeroes its hand-off counters before its next run.  conv_debug_streamk(drop, ms): test hook — helpers skip their
 // publication / the owners' wait bound in milliseconds (0 = the 2 s default).
-unsigned* conv_error_words();
-bool conv_take_error(std::string& msg);
+unsigned* conv_error_words();                 // the process-wide record (launches whose ConvArgs::sk_err is null: the single-kernel test entry points)
+unsigned* conv_error_record_new();            // a record of a Net's own (host-mapped, 64 B); ConvArgs::sk_err of its launches
+void conv_error_record_release(unsigned* r);
+bool conv_take_error(std::string& msg, unsigned* rec);   // consumes THIS record's report, if any
+bool conv_error_pending(const unsigned* rec); // a reported time-out has not been consumed yet
 unsigned conv_error_generation();
 void conv_debug_streamk(int drop_publish, int timeout_ms);
 unsigned conv_debug_generation();             // bumped by conv_debug_streamk (its settings are kernel arguments: captured graphs hold them)

@@ -567,7 +567,7 @@ void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, floa
     const long NTp = wino_rows(NT);                          // rows per frequency plane, padded to whole GEMM tiles
     KernelTimer& timer = KernelTimer::get();
     ConvArgs g{};
-    g.in = V; g.wt = wt36; g.out1 = M; g.slabs = a.slabs; g.sk_enable = a.sk_enable; g.cus = a.cus;
+    g.in = V; g.wt = wt36; g.out1 = M; g.slabs = a.slabs; g.sk_err = a.sk_err; g.sk_enable = a.sk_enable; g.cus = a.cus;
     g.B = (int)(36 * NTp); g.H = g.W = g.Ho = g.Wo = 1; g.Cin = a.Cin; g.Cout = a.Cout; g.ks = 1; g.stride = 1; g.pad = 0; g.Kpad = a.Cin;
     g.act = (int)Act::NONE; g.res_mode = (int)ResMode::NONE;
     g.wt_group_rows = (int)NTp; g.wt_gs = (long)conv_wt_rows(a.Cout) * a.Cin;

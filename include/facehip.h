@@ -110,6 +110,11 @@ FH_API float fh_compare(const float* f1, int n1, const float* f2, int n2);
 /* n pre-aligned crops [n][H][W][3] BGR u8 in HBM -> d_out [n][dim] L2-normalised; d_raw (may be
  * NULL) receives the un-normalised network output. */
 FH_API int fh_rec_embed_aligned_dev(fh_rec* r, const uint8_t* d_crops, int n, float* d_out, float* d_raw, void* stream);
+/* Waits for `stream` and reports an error a launch of THIS handle raised after its asynchronous call had already returned (today: a
+ * convolution hand-off that timed out, FH_ERR_DEVICE + fh_last_error()).  Such an error is otherwise returned by the next call
+ * on the same handle; calls on other handles never see it.  FH_OK when the queued work completed. */
+FH_API int fh_det_sync(fh_det* d, void* stream);
+FH_API int fh_rec_sync(fh_rec* r, void* stream);
 /* alignFace for n faces (d_frame_of[i] = frame index of face i, NULL = identity): writes crops
  * [n][H][W][3] and d_ok[n] (1 warped, 2 crop-resize fallback, 0 empty). */
 FH_API int fh_rec_align_dev(fh_rec* r, const uint8_t* d_frames, int rows, int cols, int step, long long frame_stride,
@@ -260,7 +265,8 @@ FH_API int fh_det_graph_stats(fh_det* d, long long* replays);
 FH_API int fh_rec_graph_stats(fh_rec* r, long long* replays);
 /* Stream-K watchdog test hook (conv_mfma.hip): drop_publish != 0 makes the helper workgroups of a remainder round "lose" their
  * publication, timeout_ms bounds the owners' wait (0 = the 2 s default).  An owner whose wait times out abandons its tile and the
- * next fh_* call returns FH_ERR_DEVICE ("stream-K hand-off timed out ...") instead of the process hanging with the GPU. */
+ * next call on the same handle (or fh_det_sync / fh_rec_sync) returns FH_ERR_DEVICE ("stream-K hand-off timed out ...") instead of
+ * the process hanging with the GPU; other handles are unaffected. */
 FH_API int fh_debug_streamk(int drop_publish, int timeout_ms);
 FH_API int fh_conv_wt_rows(int cout);
 /* host: weights [cout][ksize*ksize][cin] (O,H,W,I) -> the kernel's packed image [fh_conv_wt_rows][fh_conv_kpad] */

@@ -234,41 +234,58 @@ def test_rccl_executes_the_device_tensor_collectives_world1(tmp_path):
 def test_streamk_watchdog_turns_a_lost_handoff_into_an_error_and_recovers():
     """The stream-K owners poll a counter their helpers bump (conv_mfma.hip); forward progress rests on dispatch order, which HIP
     does not promise.  With the test hook that makes helpers LOSE their publication and a 20 ms bound, every owner must give up,
-    the launch must drain, the next synchronous call must return FH_ERR_DEVICE naming the hand-off — and after the hook is cleared
-    the same handle must give bit-identical results to a clean run (hand-off counters re-zeroed, stream-ordered)."""
+    the launch must drain, the handle's next synchronising call (fh_rec_sync) must return FH_ERR_DEVICE naming the hand-off — while a
+    SECOND recogniser handle and the handle-less calls stay clean (the record is per Net) — and after the hook is cleared the same
+    handle must give bit-identical results to a clean run (hand-off counters re-zeroed, stream-ordered)."""
     from facerecognizeonnx_amd import _lib
     rec = fa.FaceRecognizer()
-    assert rec.loadModel(models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50))
+    other = fa.FaceRecognizer()
+    path = models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50)
+    assert rec.loadModel(path) and other.loadModel(path)
     n = 37                                                               # ragged: several layers end in an owner / helper remainder round
     crops = dev(util.frames_u8(n, 112, 112, seed=12))
     L = fa.lib()
 
-    def run():
+    def run(r):
         raw = torch.zeros((n, 512), device="cuda"); out = torch.zeros((n, 512), device="cuda")
-        rc = rec.embed_aligned_dev(crops.data_ptr(), n, out.data_ptr(), raw.data_ptr())
+        rc = r.embed_aligned_dev(crops.data_ptr(), n, out.data_ptr(), raw.data_ptr())
         host = np.empty((n, 512), np.float32)
         rc2 = L.fh_memcpy_d2h(host.ctypes.data, raw.data_ptr(), host.nbytes)       # synchronous: the device has finished
         return rc, rc2, host
 
-    rc, rc2, clean = run()
+    rc, rc2, clean = run(rec)
     assert rc == n and rc2 == 0 and np.isfinite(clean).all()
+    rc, rc2, clean_other = run(other)
+    assert rc == n and rc2 == 0 and np.array_equal(clean_other, clean)
+    import time
+    t0 = time.time()
+    raw = torch.zeros((n, 512), device="cuda"); out = torch.zeros((n, 512), device="cuda")
     try:
         assert L.fh_debug_streamk(1, 20) == 0
-        import time
-        t0 = time.time()
-        try:
-            rc, rc2, _ = run()
-            assert rc2 == -3, (rc, rc2)                                  # FH_ERR_DEVICE (include/facehip.h:27)
-        except RuntimeError:                                             # (the Python mirror raises when the launching call itself saw it)
-            pass
-        dt = time.time() - t0
-        torch.cuda.synchronize()
-        msg = _lib.last_error()
-        assert "stream-K hand-off timed out" in msg and "helper arrivals" in msg, msg
-        assert dt < 30, dt                                               # bounded: 20 ms per abandoned launch, not a hang
+        assert L.fh_rec_embed_aligned_dev(rec._h, crops.data_ptr(), n, out.data_ptr(), raw.data_ptr(), None) in (n, -3)
+        torch.cuda.synchronize()                                         # every abandoned launch has drained and reported
     finally:
         assert L.fh_debug_streamk(0, 0) == 0
-    rc, rc2, again = run()
+    dt = time.time() - t0
+    assert dt < 30, dt                                                   # bounded: 20 ms per abandoned launch, not a hang
+    # the other handle and a handle-less call neither see nor consume rec's report ...
+    rc, rc2, again_other = run(other)
+    assert rc == n and rc2 == 0, (rc, rc2, _lib.last_error())
+    assert np.array_equal(again_other, clean)
+    # ... the handle itself does, once
+    assert L.fh_rec_sync(rec._h, None) == -3                             # FH_ERR_DEVICE (include/facehip.h:27)
+    msg = _lib.last_error()
+    assert "stream-K hand-off timed out" in msg and "helper arrivals" in msg, msg
+    assert L.fh_rec_sync(rec._h, None) == 0
+    with pytest.raises(RuntimeError):                                    # (and the Python mirror raises)
+        L.fh_debug_streamk(1, 20)
+        try:
+            L.fh_rec_embed_aligned_dev(rec._h, crops.data_ptr(), n, out.data_ptr(), raw.data_ptr(), None)
+            torch.cuda.synchronize()
+        finally:
+            L.fh_debug_streamk(0, 0)
+        rec.sync()
+    rc, rc2, again = run(rec)
     assert rc == n and rc2 == 0, (rc, rc2, _lib.last_error())
     assert np.array_equal(again, clean)                                  # deterministic schedule, counters back to zero
 
