@@ -153,10 +153,112 @@ __global__ __launch_bounds__(256) void dwconv3x3_hstrip_kernel(const float* __re
     }
 }
 
+// Lean form (round 4).  The two kernels above spend their time on instructions, not on memory: ~600 per thread (64-bit index arithmetic
+// with four divisions, four selects per loaded float4, an activation switch that carries the sigmoid's exp / divide) for 36 useful float4
+// FMAs — 20x20x288 at B = 128 ran 31 us against a ~15-20 us traffic floor (in + out = 118 MB, both cache-resident).  Here:
+//   * grid = (output row run, strip of rows, image): image and rows are scalars; a thread is float4 column r of the output row run
+//     [Wo][C / 4]; its centre tap is input column r (stride 1) or 2 r - c4 (stride 2), the neighbours are -+ C/4 from there, so no pixel
+//     coordinate is ever computed (the channel group c4 = r mod C/4 comes from one multiply-high);
+//   * the taps come in through BUFFER loads with a per-image descriptor: rows above / below the image are out of range and read as zero
+//     in hardware; the left / right column is pushed out of range by ONE select on its offset (not four per load);
+//   * activation is a template parameter.
+// Same summation order as the generic kernels (stride 1: columns left to right, rows inside; stride 2: rows top to bottom, columns
+// inside): bit-identical results.
+constexpr unsigned DW_OOB = 0x40000000u;                                     // an offset beyond any image (images are < 1 GB: host check)
+template <int STRIDE, int STRIP, int ACT>
+__global__ __launch_bounds__(256) void dwconv3x3_lean_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out, int H, int Lin, int Ho,
+                                                             int Lout, int C4, unsigned c4_magic, const float* __restrict__ slope) {
+    constexpr int ROWS = (STRIP - 1) * STRIDE + 3;
+    const int r = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (r >= Lout) return;
+    const int n = (int)blockIdx.z, oy0 = (int)blockIdx.y * STRIP;
+    const int c4 = r - (int)__umulhi((unsigned)r, c4_magic) * C4;           // r % C4 (c4_magic = ceil(2^32 / C4); exact for r < 2^20)
+    const int C = C4 * 4;
+    const size_t img = (size_t)H * Lin * 4;                                 // floats per input image
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in + (size_t)n * img), 0, (int)(img * 4), 0x00020000);
+    const unsigned rowb = (unsigned)Lin * 16u;
+    const int centre = STRIDE == 1 ? r : 2 * r - c4;
+    unsigned vc[3];
+    vc[1] = (unsigned)centre * 16u;
+    vc[0] = r >= C4 ? vc[1] - (unsigned)C4 * 16u : DW_OOB;
+    vc[2] = centre + C4 < Lin ? vc[1] + (unsigned)C4 * 16u : DW_OOB;
+    const unsigned row0 = (unsigned)(oy0 * STRIDE - 1) * rowb;               // (oy0 = 0: wraps to "far out of range" together with any vc)
+    v4f x[3][ROWS];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int ri = 0; ri < ROWS; ++ri)
+            x[kx][ri] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, vc[kx] + row0 + (unsigned)ri * rowb, 0, 0));
+    v4f wk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wk[t] = *reinterpret_cast<const v4f*>(w + t * C + c4 * 4);
+    const v4f b4 = *reinterpret_cast<const v4f*>(bias + c4 * 4);
+    v4f acc[STRIP];
+#pragma unroll
+    for (int o = 0; o < STRIP; ++o) acc[o] = b4;
+    if constexpr (STRIDE == 1) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int o = 0; o < STRIP; ++o)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) acc[o] += x[kx][o + ky] * wk[ky * 3 + kx];
+    } else {
+#pragma unroll
+        for (int o = 0; o < STRIP; ++o)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[o] += x[kx][o * STRIDE + ky] * wk[ky * 3 + kx];
+    }
+    v4f sl4 = v4f{0.f, 0.f, 0.f, 0.f};
+    if constexpr (ACT == (int)Act::PRELU) sl4 = *reinterpret_cast<const v4f*>(slope + c4 * 4);
+    float* __restrict__ op = out + ((size_t)n * Ho + oy0) * Lout * 4 + (size_t)r * 4;
+#pragma unroll
+    for (int o = 0; o < STRIP; ++o) {
+        if (oy0 + o >= Ho) break;
+        v4f v = acc[o];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if constexpr (ACT == (int)Act::RELU) v[e] = v[e] > 0.f ? v[e] : 0.f;
+            else if constexpr (ACT == (int)Act::PRELU) v[e] = v[e] >= 0.f ? v[e] : v[e] * sl4[e];
+        }
+        *reinterpret_cast<v4f*>(op + (size_t)o * Lout * 4) = v;
+    }
+}
+
+template <int STRIDE, int ACT>
+static void launch_dwconv3x3_lean(const float* in, const float* w9c, const float* bias, float* out, int B, int H, int W, int C, int Ho, int Wo,
+                                  const float* slope, hipStream_t s) {
+    constexpr int STRIP = STRIDE == 1 ? 4 : 2;
+    const int C4 = C / 4, Lin = W * C4, Lout = Wo * C4;
+    const unsigned magic = (unsigned)((0x100000000ull + (unsigned)C4 - 1) / (unsigned)C4);
+    hipLaunchKernelGGL((dwconv3x3_lean_kernel<STRIDE, STRIP, ACT>), dim3((unsigned)((Lout + 255) / 256), (unsigned)((Ho + STRIP - 1) / STRIP), (unsigned)B),
+                       dim3(256), 0, s, in, w9c, bias, out, H, Lin, Ho, Lout, C4, magic, slope);
+}
+template <int STRIDE>
+static void launch_dwconv3x3_lean_act(const float* in, const float* w9c, const float* bias, float* out, int B, int H, int W, int C, int Ho, int Wo,
+                                      int act, const float* slope, hipStream_t s) {
+    if (act == (int)Act::RELU) launch_dwconv3x3_lean<STRIDE, (int)Act::RELU>(in, w9c, bias, out, B, H, W, C, Ho, Wo, slope, s);
+    else if (act == (int)Act::PRELU) launch_dwconv3x3_lean<STRIDE, (int)Act::PRELU>(in, w9c, bias, out, B, H, W, C, Ho, Wo, slope, s);
+    else launch_dwconv3x3_lean<STRIDE, (int)Act::NONE>(in, w9c, bias, out, B, H, W, C, Ho, Wo, slope, s);
+}
+
 void launch_dwconv3x3(const float* in, const float* w9c, const float* bias, float* out, int B, int H, int W, int C,
                       int stride, int act, const float* slope, hipStream_t s) {
     const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
     constexpr int STRIP = 4;
+    // (row runs < 2^20 float4s: the multiply-high remainder; image < 1 GB: DW_OOB; grid y / z limits)
+    static const bool lean_on = [] { const char* e = getenv("FACEHIP_DW_LEAN"); return !e || atoi(e) != 0; }();
+    const bool lean = lean_on && (stride == 1 || stride == 2) && C >= 8 && (long)W * (C / 4) < (1L << 20) &&
+                      (long)H * W * C * 4 + (long)W * C * 4 * 8 < (long)DW_OOB && B <= 65535 && Ho <= 65535 * 2 &&
+                      (act == (int)Act::NONE || act == (int)Act::RELU || (act == (int)Act::PRELU && slope));
+    if (lean) {
+        if (stride == 1) launch_dwconv3x3_lean_act<1>(in, w9c, bias, out, B, H, W, C, Ho, Wo, act, slope, s);
+        else launch_dwconv3x3_lean_act<2>(in, w9c, bias, out, B, H, W, C, Ho, Wo, act, slope, s);
+        return;
+    }
     if (stride == 1) {
         const long total = (long)B * ((Ho + STRIP - 1) / STRIP) * Wo * (C / 4);
         hipLaunchKernelGGL((dwconv3x3_kernel<1, STRIP>), dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, in, w9c, bias, out, B, H, W, C, Ho, Wo, act, slope);

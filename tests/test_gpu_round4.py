@@ -247,3 +247,68 @@ def test_wino2_fused_conv_layer_matches_oracle(B, H, W, Cin, Cout, act, with_res
     got = out.cpu().numpy().transpose(0, 3, 1, 2)
     assert not np.isnan(got).any()
     np.testing.assert_allclose(got, ref.astype(np.float32), rtol=0, atol=5e-5)
+
+
+def _dw_graph(path, H, W, CH, stride, act, seed):
+    """input [1,3,H,W] -> Conv3x3(3 -> CH)+ReLU -> depthwise 3x3 stride `stride` (+act) -> depthwise 3x3 stride 1 (+act) -> [H'W', CH]"""
+    from facerecognizeonnx_amd.synth.onnx_writer import OnnxBuilder
+    rng = np.random.default_rng(seed)
+    b = OnnxBuilder("dw")
+    x = b.add_input("input.1", [1, 3, H, W])
+
+    def conv(x, cin, cout, stride, tag, group=1):
+        w = (rng.standard_normal((cout, cin // group, 3, 3)) * (0.6 / np.sqrt(9 * cin // group))).astype(np.float32)
+        bias = (rng.standard_normal(cout) * 0.1).astype(np.float32)
+        return b.node("Conv", [x, b.init(f"{tag}.w", w), b.init(f"{tag}.b", bias)], kernel_shape=[3, 3], strides=[stride, stride],
+                      pads=[1, 1, 1, 1], dilations=[1, 1], group=group)
+
+    def activation(x, tag):
+        if act == "relu":
+            return b.node("Relu", [x])
+        if act == "prelu":
+            return b.node("PRelu", [x, b.init(f"{tag}.slope", (0.25 * rng.uniform(0.5, 1.5, (CH, 1, 1))).astype(np.float32))])
+        return x
+
+    x = b.node("Relu", [conv(x, 3, CH, 1, "stem")])
+    x = activation(conv(x, CH, CH, stride, "dw1", group=CH), "a1")
+    x = activation(conv(x, CH, CH, 1, "dw2", group=CH), "a2")
+    x = b.node("Transpose", [x], perm=[0, 2, 3, 1])
+    b.node("Reshape", [x, b.init("shape", np.array([-1, CH], np.int64))], outputs=["out"])
+    b.add_output("out", ["A", CH])
+    return b.save(path)
+
+
+@pytest.mark.parametrize("H,W,CH,stride,act", [
+    (20, 20, 288, 1, "relu"),        # SCRFD's 20x20x288 blocks (row run 1440 float4s: six workgroups per row strip, the last one ragged)
+    (40, 40, 152, 2, "relu"),        # ... and the stride-2 entry of that stage (C / 4 = 38: not a power of two)
+    (7, 9, 8, 1, "none"),            # smallest channel count of the lean form, odd map, fewer rows than two strips
+    (9, 7, 8, 2, "prelu"),           # odd W at stride 2: the right tap of the last column is out of the map
+    (13, 31, 20, 1, "prelu"),        # H not a multiple of the strip
+    (33, 17, 64, 2, "none"),         # odd H at stride 2: the bottom tap row of the last output row is out of the map
+    (5, 5, 4, 1, "relu"),            # C = 4: the generic kernel (no lean form below 8 channels)
+])
+def test_depthwise_lean_kernel_matches_oracle(tmp_path, H, W, CH, stride, act):
+    """dwconv3x3_lean_kernel (ops_misc.hip): buffer-load taps (rows outside the image read as zero in hardware, edge columns pushed out of
+    range by one select), the multiply-high channel index, both strides, all three activations, two images (per-image descriptors) —
+    against the oracle's graph runner on the same preprocessed input."""
+    from oracle import onnx_min
+    path = _dw_graph(str(tmp_path / "dw.onnx"), H, W, CH, stride, act, seed=H * 100 + W + CH)
+    det = fa.FaceDetector()
+    assert det.loadModel(path)
+    assert det.input_size() == (W, H)
+    n = 2
+    img = util.frames_u8(n, H, W, seed=7 + CH, smooth=False)
+    d = torch.from_numpy(img).cuda()
+    assert fa.lib().fh_det_run_network_dev(det.handle, d.data_ptr(), n, H, W, W * 3, H * W * 3, None) == n
+    torch.cuda.synchronize()
+    r, c = C.c_int(), C.c_int()
+    p = fa.lib().fh_det_output_dev(det.handle, 0, C.byref(r), C.byref(c))
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    assert (r.value, c.value) == (Ho * Wo, CH), (r.value, c.value)
+    got = np.empty((n, Ho * Wo, CH), np.float32)
+    assert fa.lib().fh_memcpy_d2h(got.ctypes.data, p, got.nbytes) == 0
+    g = onnx_min.load(path)
+    for i in range(n):
+        inp, _ = oracle.det_preprocess(img[i], W, H)
+        ref = oracle.run_graph(g, {"input.1": inp[None]})["out"]
+        np.testing.assert_allclose(got[i], np.asarray(ref).reshape(Ho * Wo, CH), rtol=1e-5, atol=1e-5, err_msg=f"image {i}")
