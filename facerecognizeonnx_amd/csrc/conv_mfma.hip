@@ -92,9 +92,13 @@ struct Tile {
 // its stores: on this ISA loads and stores share one in-order counter (vmcnt), so a load issued after a store can only be waited for
 // together with that store's acknowledgement — bias / slope loads interleaved with the stores turned the epilogue into a chain of
 // store round trips (16 per 256x64 tile, a third of the tile's time).  The residual reads are issued up front for the same reason.
+// whole-line epilogue (conv_epilogue: tr) when rows are whole 128-byte lines; ep_direct = A / B switch (FACEHIP_EP_DIRECT): 1 = never,
+// 3 = for every Cout % 4 == 0 (measured: the 16-channel FPN laterals lose 5 % to their idle tail lanes)
+__device__ __forceinline__ bool conv_ep_lines(const ConvArgs& p) { return p.ep_direct == 0 ? (p.Cout & 31) == 0 : p.ep_direct == 3; }
 template <int BM, int BN, int WM, int WN>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM / WM / 32][BN / WN / 32], int m0, int n0,
-                                              int wm, int wn, int lane, int only_i = -1, int only_j = -1, const float* ep = nullptr) {
+                                              int wm, int wn, int lane, int only_i = -1, int only_j = -1, const float* ep = nullptr,
+                                              float* tr = nullptr) {
     using TL = Tile<BM, BN, WM, WN>;
     const int fr = lane & 31, fh2 = lane >> 5;
     const int HoWo = p.Ho * p.Wo;
@@ -120,6 +124,73 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
                     const int cg = p.oc0[g + 1] - p.oc0[g];
                     const float v = apply_act(acc[i][j][e] + p.bias[co], p.oact[g], 0.f);
                     p.outs[g][(size_t)m * cg + (co - p.oc0[g])] = v;
+                }
+            }
+        }
+        return;
+    }
+    if (ep && vec && tr && only_i < 0 && only_j < 0) {
+        // Whole-line form (round 4).  A lane's accumulators are 4-channel pieces of ITS pixel row: written straight from registers, one
+        // store instruction puts 32 bytes into each of 32 rows — a quarter of a 128-byte line per row, 8 instructions (and 8 residual
+        // reads) per line.  Here each 32 x 32 block is turned around in a wave-private LDS scratch (tr: [waves][32 rows][36 floats], the
+        // 16 lanes of a b128 phase hit different banks on the write side) and a lane takes float4 column cq of rows rr, rr + 8, rr + 16,
+        // rr + 24: one instruction then moves 8 rows x ONE whole line, for stores and residual reads alike, and the per-channel vectors of
+        // a block are the same for all four of a lane's rows (whole lines when Cout % 32 == 0, whole 128-byte runs otherwise).  Same arithmetic
+        // per element: bit-identical results.
+        float* const blk = tr + (wm * WN + wn) * (32 * 36);
+        const int rr = lane >> 3, cq = lane & 7;
+#pragma unroll
+        for (int i = 0; i < TL::TM; ++i) {
+            const int mb = m0 + (wm * TL::TM + i) * 32 + rr;               // this lane's rows: mb + 8 k
+            int cls4 = 0;                                                   // border class of row k in bits 4k .. 4k+3
+            if (p.bias_cls) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int mc = min(mb + 8 * k, M - 1);
+                    const int n = mc / HoWo, rem = mc - n * HoWo;
+                    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                    cls4 |= (3 * (oy == 0 ? 0 : oy == p.Ho - 1 ? 2 : 1) + (ox == 0 ? 0 : ox == p.Wo - 1 ? 2 : 1)) << (4 * k);
+                }
+            }
+            auto res_row = [&](int m) -> size_t {
+                if (p.res_mode != (int)ResMode::UP2X) return (size_t)m * p.Cout;
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                return ((size_t)(n * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * p.Cout;
+            };
+#pragma unroll
+            for (int j = 0; j < TL::TN; ++j) {
+                const int cl = (wn * TL::TN + j) * 32 + 4 * cq;            // channel within the tile
+                const int co = n0 + cl;
+                if (n0 + (wn * TL::TN + j) * 32 >= p.Cout) continue;       // (a padded column block; wave-uniform)
+                const bool cok = co < p.Cout;                              // (the last block of a Cout that is not a multiple of 32: its tail lanes idle)
+                v4f r4[4];
+                if (p.res_mode != (int)ResMode::NONE) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) r4[k] = cok ? *reinterpret_cast<const v4f*>(res + res_row(min(mb + 8 * k, M - 1)) + co) : v4f{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<v4f*>(blk + fr * 36 + 8 * g + 4 * fh2) = v4f{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                v4f sl = {0.f, 0.f, 0.f, 0.f};
+                if (p.act == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(ep + 9 * BN + cl);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int m = mb + 8 * k;
+                    const v4f a4 = *reinterpret_cast<const v4f*>(blk + (rr + 8 * k) * 36 + 4 * cq);
+                    const v4f b4 = *reinterpret_cast<const v4f*>(ep + ((cls4 >> (4 * k)) & 15) * BN + cl);
+                    v4f v;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = apply_act(a4[c] + b4[c], p.act, sl[c]);
+                    if (p.res_mode != (int)ResMode::NONE) v += r4[k];
+                    if (m < M && cok) {
+                        const size_t row = (size_t)m * p.Cout + co;
+                        if (out1) *reinterpret_cast<v4f*>(out1 + row) = v;
+                        if (out2) {
+                            const v4f s2 = *reinterpret_cast<const v4f*>(ep + 10 * BN + cl), t2 = *reinterpret_cast<const v4f*>(ep + 11 * BN + cl);
+                            *reinterpret_cast<v4f*>(out2 + row) = v * s2 + t2;
+                        }
+                    }
                 }
             }
         }
@@ -570,7 +641,9 @@ __global__ __launch_bounds__(WM * WN * 64, OCC) void conv_igemm_kernel(const Con
             }
             __syncthreads();
         }
-        conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane, -1, -1, use_ep ? ep : nullptr);
+        // (the transposition scratch of the whole-line epilogue sits behind the 12 x BN vectors: both fit the tile buffers of every shape)
+        static_assert((12 * BN + WM * WN * 32 * 36) * sizeof(float) <= sizeof(lds), "epilogue scratch");
+        conv_epilogue<BM, BN, WM, WN>(p, acc, m0, n0, wm, wn, lane, -1, -1, use_ep ? ep : nullptr, use_ep && conv_ep_lines(p) ? ep + 12 * BN : nullptr);
     } while (role == HELPER && hu < hu_end);
 }
 
@@ -880,7 +953,8 @@ __global__ __launch_bounds__(256, OCC) void conv_pw_kernel(const ConvArgs p, con
         if (e < 12 * BN) ep[e] = epv[k];
     }
     __syncthreads();
-    conv_epilogue<BM, BN, 4, 1>(p, acc, m0, n0, wid, 0, lane, -1, -1, ep);
+    static_assert((12 * BN + 4 * 32 * 36) * sizeof(float) <= sizeof(lds), "epilogue scratch");
+    conv_epilogue<BM, BN, 4, 1>(p, acc, m0, n0, wid, 0, lane, -1, -1, ep, conv_ep_lines(p) ? ep + 12 * BN : nullptr);
 }
 
 template <int BN, int OCC>
@@ -892,6 +966,10 @@ static void launch_pw_cfg(const ConvArgs& a, long M, hipStream_t s) {
     timer.end(s, 11, a.t_flops, a.t_bytes);
 }
 
+static int ep_direct_env() {                         // FACEHIP_EP_DIRECT=1: the epilogues store straight from the accumulator registers (A / B timing)
+    static const int v = [] { const char* e = getenv("FACEHIP_EP_DIRECT"); return e ? atoi(e) : 0; }();
+    return v;
+}
 // true = launched
 static bool launch_pw(ConvArgs a, hipStream_t s) {
     static int on = -1;
@@ -901,6 +979,7 @@ static bool launch_pw(ConvArgs a, hipStream_t s) {
         (M & 127) || a.H != a.Ho || a.W != a.Wo || a.Kpad % 32 || a.Kpad < a.Cin)
         return false;
     a.zeros = conv_zero_line();
+    a.ep_direct = ep_direct_env();
     const int cus = a.cus > 0 ? a.cus : conv_num_cus();
     auto cols = [&](int bn) { return (a.Cout + bn - 1) / bn * bn; };
     // widest tile whose padded columns cost <= 7 %; the 32-wide one otherwise (the generic kernel pads the same way)
@@ -1140,6 +1219,7 @@ static void launch_cfg_tail(ConvArgs a, int resident_per_cu, int cfg_tag, hipStr
     if (!helpers) { full = T; R = 0; }
     a.sk_full = full; a.sk_helpers = helpers; a.sk_rem = R;
     a.sk_err = owners ? (a.sk_err ? a.sk_err : conv_error_words()) : nullptr; a.sk_timeout = g_sk_timeout; a.sk_test_drop = g_sk_test_drop;
+    a.ep_direct = ep_direct_env();
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
     const dim3 grid((unsigned)(full + helpers + owners));

@@ -95,6 +95,7 @@ struct ConvArgs {
     // stream-K watchdog (filled in by launch_conv): host-visible error record, the owners' wait bound in 2^16 ticks of the 100 MHz
     // wall clock, and the test hook that makes helpers "lose" their publication
     unsigned* sk_err;
+    int ep_direct;                  // tuning hook (FACEHIP_EP_DIRECT): 1 = epilogue stores straight from the accumulator registers, 3 = whole-line form for every Cout % 4 == 0
     unsigned sk_timeout;
     int sk_test_drop;
     int tile0;              // filled in by launch_conv: first tile conv_igemm_kernel computes (the tiles before it ran in conv_tall_kernel)

@@ -339,7 +339,9 @@ __device__ __forceinline__ int wino_plane_freq(const WinoPlanes& pl, const int t
     return 6 * i + j;
 }
 
-template <int BN, int OCC>
+// ABL (diagnostic instantiations only, results are garbage): 1 = no loads in the K loop (the first chunk is computed over and over),
+// 2 = no LDS reads (operands stay in registers), 4 = no barriers in the K loop, 8 = no stores, 16 = stores straight from registers
+template <int BN, int OCC, int ABL = 0>
 __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M,
                                                             const int K, const int N, const WinoPlanes pl, const long wt_gs,
                                                             const int tiles_n, const int chunks) {
@@ -378,24 +380,67 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __rest
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
     load_chunk(0);
     __syncthreads();
+    v4f xk = v4f{0.f, 0.f, 0.f, 0.f}, wk[TN];
+    if constexpr ((ABL & 2) != 0) {
+        xk = lds[0][(wid * 32 + fr) * 8 + (fh2 ^ fsw)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wk[j] = lds[0][BM * 8 + fr * 8 + j * 32 * 8 + (fh2 ^ fsw)];
+    }
     for (int kc = 0; kc < chunks; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < chunks) load_chunk(buf ^ 1);
+        const int buf = (ABL & 1) ? 0 : (kc & 1);
+        if ((ABL & 1) == 0 && kc + 1 < chunks) load_chunk(buf ^ 1);
         const v4f* X = lds[buf] + (wid * 32 + fr) * 8;
         const v4f* Wt = lds[buf] + BM * 8 + fr * 8;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int col = (2 * s + fh2) ^ fsw;
-            const v4f xv = X[col];
+            v4f xv;
             v4f w[TN];
+            if constexpr ((ABL & 2) != 0) {
+                xv = xk;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) w[j] = Wt[j * 32 * 8 + col];
+                for (int j = 0; j < TN; ++j) w[j] = wk[j];
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(xv));                  // (opaque: the compiler must not fold the steps together)
+#endif
+            } else {
+                xv = X[col];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) w[j] = Wt[j * 32 * 8 + col];
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j][e], xv[e], acc[j], 0, 0, 0);
         }
-        __syncthreads();
+        if constexpr ((ABL & 4) == 0) __syncthreads();
+    }
+    if constexpr ((ABL & 8) != 0) { if (acc[0][0] != 123.456f) return; }
+    // Stores.  A lane's accumulators are 4-column pieces of ITS row: stored straight from registers, one instruction writes 32 bytes to
+    // each of 32 rows (a quarter of a 128-byte line each, 8 instructions per row).  Instead the wave turns its 32 x BN block around in
+    // LDS (its own region of the tile buffers, which every wave has finished reading at the loop's last barrier; row pitch BN + 4 floats:
+    // the 16 lanes of a b128 phase hit 64 different banks) and stores whole rows: 64 / (BN / 4) rows x BN * 4 contiguous bytes per instruction.
+    if constexpr ((ABL & 16) == 0) {
+        constexpr int JB = TN >= 2 ? 2 : 1, W = JB * 32;                    // column blocks turned around at a time (BN = 128: two halves)
+        constexpr int PITCH = W + 4, RPI = 64 / (W / 4);                    // floats per LDS row; rows per store instruction
+        static_assert(TN % JB == 0 && 4 * 32 * PITCH * sizeof(float) <= sizeof(lds), "store scratch");
+        float* const blk = reinterpret_cast<float*>(&lds[0][0]) + wid * 32 * PITCH;
+        const int rr = lane / (W / 4), cq = lane % (W / 4);
+#pragma unroll
+        for (int h = 0; h < TN / JB; ++h) {
+#pragma unroll
+            for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int j = h * JB + jj;
+                    *reinterpret_cast<v4f*>(blk + fr * PITCH + jj * 32 + 8 * g + 4 * fh2) = v4f{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                }
+            float* const obase = M + (size_t)(m0 + wid * 32 + rr) * N + n0 + h * W + 4 * cq;
+#pragma unroll
+            for (int i = 0; i < 32 / RPI; ++i)
+                *reinterpret_cast<v4f*>(obase + (size_t)i * RPI * N) = *reinterpret_cast<const v4f*>(blk + (rr + i * RPI) * PITCH + 4 * cq);
+        }
+        return;
     }
     float* orow = M + (size_t)(m0 + wid * 32 + fr) * N + n0 + 4 * fh2;
 #pragma unroll
@@ -529,9 +574,11 @@ static int wino_mix_enabled() {
     return v;
 }
 
-static bool wino_bn128(bool mixed) {                           // tuning hook: 1 = 128x128 GEMM tiles for the mixed layout, 2 = everywhere
+// 128x128 GEMM tiles: 1 = for the mixed layout (default since the stores are whole lines: 14x14x256 76.7 -> 74.5 us at B = 128 — a third
+// less L2 -> LDS traffic per FLOP; before that the two tile shapes were level), 2 = everywhere (28x28 and 7x7 lose), 0 = never
+static bool wino_bn128(bool mixed) {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("FACEHIP_WINO_BN128"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char* e = getenv("FACEHIP_WINO_BN128"); v = e ? atoi(e) : 1; }
     return v == 2 || (v == 1 && mixed);
 }
 
@@ -598,9 +645,19 @@ void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, floa
         } else if (wide && a.Cout % 128 == 0 && wino_bn128(mix != nullptr))
             hipLaunchKernelGGL((wino_gemm_kernel<128, 2>), dim3((unsigned)((rows / 128) * (a.Cout / 128))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
                                pl, g.wt_gs, a.Cout / 128, chunks);
-        else if (wide)
+        else if (wide) {
+#ifdef FACEHIP_WINO_ABL
+            static const int abl = [] { const char* e = getenv("FACEHIP_WINO_ABL"); return e ? atoi(e) : 0; }();
+            const dim3 grid((unsigned)((rows / 128) * (a.Cout / 64)));
+#define WABL(X) case X: hipLaunchKernelGGL((wino_gemm_kernel<64, 3, X>), grid, dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout, pl, g.wt_gs, a.Cout / 64, chunks); break;
+            switch (abl) { WABL(1) WABL(2) WABL(3) WABL(4) WABL(5) WABL(6) WABL(7) WABL(8) WABL(15) WABL(16) WABL(17) WABL(24)
+                default: hipLaunchKernelGGL((wino_gemm_kernel<64, 3>), grid, dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout, pl, g.wt_gs, a.Cout / 64, chunks); }
+#undef WABL
+#else
             hipLaunchKernelGGL((wino_gemm_kernel<64, 3>), dim3((unsigned)((rows / 128) * (a.Cout / 64))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
                                pl, g.wt_gs, a.Cout / 64, chunks);
+#endif
+        }
         else
             hipLaunchKernelGGL((wino_gemm_kernel<32, 4>), dim3((unsigned)((rows / 128) * (a.Cout / 32))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
                                pl, g.wt_gs, a.Cout / 32, chunks);
