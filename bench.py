@@ -36,7 +36,7 @@ F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 BF16_MFMA_PEAK_TFLOPS = 2516.8    # the same table: BF16 MFMA = 16x the f32 matrix rate, dense (~2.5 PF)
 CFG_NAMES = ["conv_igemm_kernel<128,128,2,2>", "conv_igemm_kernel<256,64,4,1>", "conv_igemm_kernel<128,32,4,1>",
              "conv_igemm_kernel<64,64,2,2>", "dwpw_kernel (incl. the fused stem front) + dwconv3x3 kernels", "other graph ops (incl. stem_conv_u8)",
-             "conv_fixup_kernel", "wino_gemm_kernel<64, 3>", "wino_input_kernel + wino_output_kernel + wino_fused_kernel + wino_mix_kernel",
+             "conv_fixup_kernel", "wino_gemm_kernel<64, 3> / <128, 2>", "wino_input_kernel + wino_output_kernel + wino_fused_kernel + wino_mix_kernel",
              "conv3x3_halo_kernel", "conv_tall_kernel<256,64,4,1> / <128,32,4,1>", "conv_pw_kernel<96|64|32>",
              "wino2_kernel<4|2> (fused F(2x2,3x3))"]
 NTAGS = len(CFG_NAMES)
