@@ -79,6 +79,11 @@ with open(os.path.join(dst, f"{tag}_traffic.csv"), "w") as f:
         traffic[k] = rd + wr
         f.write(f"\"{k}\",{n},{v['fetch_kib']:.0f},{v['write_kib']:.0f},{rd:.0f},{wr:.0f},{rd + wr:.0f}\n")
 
+# bench.py books the Winograd GEMM's tile widths under one timer tag: the same aggregate here (launch-weighted)
+wg = [(k, v) for k, v in agg.items() if k.startswith("wino_gemm_kernel<")]
+if wg:
+    n = sum(max(v["launches"], 1) for _, v in wg)
+    traffic["wino_gemm_kernel<64, 3> / <128, 2>"] = sum(2.0 * v["fetch_kib"] * 1024 + v["write_kib"] * 1024 for _, v in wg) / n
 tj_path = os.path.join(dst, "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
 tj[workload] = traffic
