@@ -339,6 +339,34 @@ __device__ __forceinline__ int wino_plane_freq(const WinoPlanes& pl, const int t
     return 6 * i + j;
 }
 
+// A wave's 32 x (32 TN) accumulator block -> M as whole rows (see the comment at wino_gemm_kernel's stores): turned around in the wave's
+// own region of `scratch` (the tile buffers, free after the K loop's last barrier), two 32-column blocks at a time.
+template <int TN>
+__device__ __forceinline__ void wino_store_lines(const v16f (&acc)[TN], float* scratch, size_t scratch_bytes, float* __restrict__ M, int N,
+                                                 int m0, int n0, int wid, int lane) {
+    constexpr int JB = TN >= 2 ? 2 : 1, W = JB * 32;                        // column blocks turned around at a time (BN = 128: two halves)
+    constexpr int PITCH = W + 4, RPI = 64 / (W / 4);                        // floats per LDS row; rows per store instruction
+    static_assert(TN % JB == 0, "store scratch");
+    (void)scratch_bytes;
+    const int fr = lane & 31, fh2 = lane >> 5;
+    float* const blk = scratch + wid * 32 * PITCH;
+    const int rr = lane / (W / 4), cq = lane % (W / 4);
+#pragma unroll
+    for (int h = 0; h < TN / JB; ++h) {
+#pragma unroll
+        for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int j = h * JB + jj;
+                *reinterpret_cast<v4f*>(blk + fr * PITCH + jj * 32 + 8 * g + 4 * fh2) = v4f{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+            }
+        float* const obase = M + (size_t)(m0 + wid * 32 + rr) * N + n0 + h * W + 4 * cq;
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i)
+            *reinterpret_cast<v4f*>(obase + (size_t)i * RPI * N) = *reinterpret_cast<const v4f*>(blk + (rr + i * RPI) * PITCH + 4 * cq);
+    }
+}
+
 // ABL (diagnostic instantiations only, results are garbage): 1 = no loads in the K loop (the first chunk is computed over and over),
 // 2 = no LDS reads (operands stay in registers), 4 = no barriers in the K loop, 8 = no stores, 16 = stores straight from registers
 template <int BN, int OCC, int ABL = 0>
@@ -421,25 +449,8 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __rest
     // LDS (its own region of the tile buffers, which every wave has finished reading at the loop's last barrier; row pitch BN + 4 floats:
     // the 16 lanes of a b128 phase hit 64 different banks) and stores whole rows: 64 / (BN / 4) rows x BN * 4 contiguous bytes per instruction.
     if constexpr ((ABL & 16) == 0) {
-        constexpr int JB = TN >= 2 ? 2 : 1, W = JB * 32;                    // column blocks turned around at a time (BN = 128: two halves)
-        constexpr int PITCH = W + 4, RPI = 64 / (W / 4);                    // floats per LDS row; rows per store instruction
-        static_assert(TN % JB == 0 && 4 * 32 * PITCH * sizeof(float) <= sizeof(lds), "store scratch");
-        float* const blk = reinterpret_cast<float*>(&lds[0][0]) + wid * 32 * PITCH;
-        const int rr = lane / (W / 4), cq = lane % (W / 4);
-#pragma unroll
-        for (int h = 0; h < TN / JB; ++h) {
-#pragma unroll
-            for (int jj = 0; jj < JB; ++jj)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int j = h * JB + jj;
-                    *reinterpret_cast<v4f*>(blk + fr * PITCH + jj * 32 + 8 * g + 4 * fh2) = v4f{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
-                }
-            float* const obase = M + (size_t)(m0 + wid * 32 + rr) * N + n0 + h * W + 4 * cq;
-#pragma unroll
-            for (int i = 0; i < 32 / RPI; ++i)
-                *reinterpret_cast<v4f*>(obase + (size_t)i * RPI * N) = *reinterpret_cast<const v4f*>(blk + (rr + i * RPI) * PITCH + 4 * cq);
-        }
+        static_assert(4 * 32 * ((TN >= 2 ? 64 : 32) + 4) * sizeof(float) <= sizeof(lds), "store scratch");
+        wino_store_lines<TN>(acc, reinterpret_cast<float*>(&lds[0][0]), sizeof(lds), M, N, m0, n0, wid, lane);
         return;
     }
     float* orow = M + (size_t)(m0 + wid * 32 + fr) * N + n0 + 4 * fh2;
@@ -520,12 +531,8 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_bf16x2_kernel(const float*
         }
         __syncthreads();
     }
-    float* orow = M + (size_t)(m0 + wid * 32 + fr) * N + n0 + 4 * fh2;
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<v4f*>(orow + j * 32 + 8 * g) = v4f{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+    static_assert(4 * 32 * ((TN >= 2 ? 64 : 32) + 4) * sizeof(float) <= sizeof(lds), "store scratch");
+    wino_store_lines<TN>(acc, reinterpret_cast<float*>(&lds[0][0]), sizeof(lds), M, N, m0, n0, wid, lane);
 }
 
 long wino_rows(long tiles) { return (tiles + 255) / 256 * 256; }   // rows of one frequency plane: whole tiles of every GEMM configuration
