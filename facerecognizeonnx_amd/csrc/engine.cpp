@@ -326,7 +326,11 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
     for (auto& op : plan_.ops) { std::vector<float>().swap(op.weight); }
 }
 
-Net::SkRecord::~SkRecord() { conv_error_record_release(p); }
+Net::SkRecord::~SkRecord() {
+    if (!p) return;
+    (void)hipDeviceSynchronize();                         // no launch of this Net can write the record once it is back on the free list
+    conv_error_record_release(p);
+}
 
 void Net::reserve(int max_batch) {
     if (max_batch <= cap_) return;
