@@ -1,7 +1,7 @@
 #!/bin/bash
 # Ablation timing of wino_gemm_kernel<64, 3> (winograd.hip): a diagnostic build (-DFACEHIP_WINO_ABL) installed as a SIDE copy of the
 # library (FACEHIP_LIB), then the recogniser's layer table per switch combination (bits: 1 = no loads in the K loop, 2 = no LDS reads,
-# 4 = no barriers in the K loop, 8 = no stores, 16 = stores straight from the accumulator registers, 32 = every load reads the same 3 KB).
+# 4 = no barriers in the K loop, 8 = no stores, 16 = stores straight from the accumulator registers).
 # FACEHIP_WINO_BN128=0: the ablated instantiations exist for the 128 x 64 tile only.  Results of an ablated run are wrong by construction; only the kernel times are read.
 set -e
 cd "$(dirname "$0")/.."
