@@ -312,3 +312,24 @@ def test_depthwise_lean_kernel_matches_oracle(tmp_path, H, W, CH, stride, act):
         inp, _ = oracle.det_preprocess(img[i], W, H)
         ref = oracle.run_graph(g, {"input.1": inp[None]})["out"]
         np.testing.assert_allclose(got[i], np.asarray(ref).reshape(Ho * Wo, CH), rtol=1e-5, atol=1e-5, err_msg=f"image {i}")
+
+
+def test_handle_sync_entry_points():
+    """fh_det_sync / fh_rec_sync: wait for a stream and report a handle's deferred errors — FH_OK on a healthy handle (also right after an
+    asynchronous call on that stream), FH_ERR_ARG on a null handle."""
+    L = fa.lib()
+    det = fa.FaceDetector(); rec = fa.FaceRecognizer()
+    assert det.loadModel(models.cached("det_500m_seed100.onnx", models.make_det_500m))
+    assert rec.loadModel(models.cached("w600k_r50_seed200.onnx", models.make_w600k_r50))
+    assert L.fh_det_sync(det.handle, None) == 0 and L.fh_rec_sync(rec._h, None) == 0
+    s = torch.cuda.Stream()
+    crops = dev(util.frames_u8(5, 112, 112, seed=4))
+    out = torch.zeros((5, 512), device="cuda")
+    torch.cuda.synchronize()
+    assert rec.embed_aligned_dev(crops.data_ptr(), 5, out.data_ptr(), 0, s.cuda_stream) == 5
+    rec.sync(s.cuda_stream)                                               # returns only once the embeddings are complete
+    host = np.empty((5, 512), np.float32)
+    assert L.fh_memcpy_d2h(host.ctypes.data, out.data_ptr(), host.nbytes) == 0
+    assert np.allclose(np.linalg.norm(host, axis=1), 1.0, atol=1e-5)
+    det.sync()
+    assert L.fh_det_sync(None, None) == -1 and L.fh_rec_sync(None, None) == -1
