@@ -57,6 +57,25 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr size_t SK_SLAB_FLOATS = (size_t)2 * 1280 * 128 * 128;
 constexpr size_t SK_COUNTERS = 4096;
 
+// The same with the activation a compile-time constant: the epilogues' hot paths switch ONCE per tile (with_act) instead of running
+// apply_act's branch tree per element — inlined 16 times per 32 x 32 block it made the epilogue thousands of basic blocks
+// (phase stamps of conv_pw_kernel, scripts/pw_ablate.sh: first block in LDS -> last store issued 7.7 -> 5.8 us of a 37 us tile).
+template <int A>
+__device__ __forceinline__ float act_c(float v, float slope) {
+    if constexpr (A == (int)Act::RELU) return v > 0.f ? v : 0.f;
+    else if constexpr (A == (int)Act::PRELU) return v >= 0.f ? v : v * slope;
+    else if constexpr (A == (int)Act::SIGMOID) return 1.0f / (1.0f + expf(-v));
+    else return v;
+}
+template <int A> struct ActC { static constexpr int value = A; };
+template <class F>
+__device__ __forceinline__ void with_act(int act, F&& f) {
+    if (act == (int)Act::RELU) f(ActC<(int)Act::RELU>{});
+    else if (act == (int)Act::PRELU) f(ActC<(int)Act::PRELU>{});
+    else if (act == (int)Act::SIGMOID) f(ActC<(int)Act::SIGMOID>{});
+    else f(ActC<(int)Act::NONE>{});
+}
+// ds_write_b128 the compiler does not see (p points into LDS; ordered before later LDS accesses of the wave by the LDS queue itself)
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     if (act == (int)Act::RELU) return v > 0.f ? v : 0.f;
     if (act == (int)Act::PRELU) return v >= 0.f ? v : v * slope;
@@ -139,6 +158,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
         // per element: bit-identical results.
         float* const blk = tr + (wm * WN + wn) * (32 * 36);
         const int rr = lane >> 3, cq = lane & 7;
+#ifdef FACEHIP_PW_ABL
+        const unsigned long long est0 = wall_clock64();
+        unsigned long long est1 = 0, est2 = 0, est3 = 0;
+#endif
+        // Loads and stores share ONE in-order counter (vmcnt): a wait for a residual load that sits behind a store in program order is a
+        // wait for that store's acknowledgement (~0.36 us; with the residual a run-time flag the compiler kept such a wait in front of every
+        // row group even when there was no residual).  So the residual is a compile-time flag here, a block's residual reads are issued
+        // first and consumed two row groups at a time BEFORE those groups' stores.  (What remains between blocks is the compiler's
+        // vmcnt(0) in front of the next block's LDS stores — it protects the registers the pending global stores read; giving every stored
+        // value a register of its own removed it and changed nothing: the tile's 48 KB leave at the chip's ~5 TB/s write rate together
+        // with every other workgroup's, scripts/pw_phases.py.)
+        auto body = [&](auto AC, auto RC) {
+        constexpr int A = decltype(AC)::value;
+        constexpr bool R = decltype(RC)::value != 0;
 #pragma unroll
         for (int i = 0; i < TL::TM; ++i) {
             const int mb = m0 + (wm * TL::TM + i) * 32 + rr;               // this lane's rows: mb + 8 k
@@ -165,40 +198,75 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
                 if (n0 + (wn * TL::TN + j) * 32 >= p.Cout) continue;       // (a padded column block; wave-uniform)
                 const bool cok = co < p.Cout;                              // (the last block of a Cout that is not a multiple of 32: its tail lanes idle)
                 v4f r4[4];
-                if (p.res_mode != (int)ResMode::NONE) {
+                if constexpr (R) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) r4[k] = cok ? *reinterpret_cast<const v4f*>(res + res_row(min(mb + 8 * k, M - 1)) + co) : v4f{0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<v4f*>(blk + fr * 36 + 8 * g + 4 * fh2) = v4f{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                v4f sl = {0.f, 0.f, 0.f, 0.f};
-                if (p.act == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(ep + 9 * BN + cl);
+                v4f sl = {0.f, 0.f, 0.f, 0.f}, s2 = sl, t2 = sl;
+                if constexpr (A == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(ep + 9 * BN + cl);
+                if (out2) { s2 = *reinterpret_cast<const v4f*>(ep + 10 * BN + cl); t2 = *reinterpret_cast<const v4f*>(ep + 11 * BN + cl); }
+#ifdef FACEHIP_PW_ABL
+                if (i == 0 && j == 0) est1 = wall_clock64();                // first block's accumulators written to LDS (issued)
+#endif
+                // (two row groups at a time: their arithmetic, then their stores — four at a time spill in the 128-register instantiations)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int m = mb + 8 * k;
-                    const v4f a4 = *reinterpret_cast<const v4f*>(blk + (rr + 8 * k) * 36 + 4 * cq);
-                    const v4f b4 = *reinterpret_cast<const v4f*>(ep + ((cls4 >> (4 * k)) & 15) * BN + cl);
-                    v4f v;
+                for (int h = 0; h < 2; ++h) {
+                    v4f vk[2];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = apply_act(a4[c] + b4[c], p.act, sl[c]);
-                    if (p.res_mode != (int)ResMode::NONE) v += r4[k];
-                    if (m < M && cok) {
-                        const size_t row = (size_t)m * p.Cout + co;
-                        if (out1) *reinterpret_cast<v4f*>(out1 + row) = v;
-                        if (out2) {
-                            const v4f s2 = *reinterpret_cast<const v4f*>(ep + 10 * BN + cl), t2 = *reinterpret_cast<const v4f*>(ep + 11 * BN + cl);
-                            *reinterpret_cast<v4f*>(out2 + row) = v * s2 + t2;
+                    for (int q = 0; q < 2; ++q) {
+                        const int k = 2 * h + q;
+                        const v4f a4 = *reinterpret_cast<const v4f*>(blk + (rr + 8 * k) * 36 + 4 * cq);
+                        const v4f b4 = *reinterpret_cast<const v4f*>(ep + ((cls4 >> (4 * k)) & 15) * BN + cl);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) vk[q][c] = act_c<A>(a4[c] + b4[c], sl[c]);
+                        if constexpr (R) vk[q] += r4[k];
+                    }
+#if defined(__HIP_DEVICE_COMPILE__)
+                    __builtin_amdgcn_sched_barrier(0);                      // (every wait of this half lies above its stores)
+#endif
+#ifdef FACEHIP_PW_ABL
+                    if (i == 0 && j == 0 && h == 0) est2 = wall_clock64();  // first block's first values ready
+#endif
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int m = mb + 8 * (2 * h + q);
+#ifdef FACEHIP_PW_ABL
+                        if ((p.sk_test_drop & 16) && lane != 0) continue;  // (diagnostic: every instruction of the epilogue but 63 of 64 lanes' stores)
+#endif
+                        if (m < M && cok) {
+                            const size_t row = (size_t)m * p.Cout + co;
+                            if (out1) *reinterpret_cast<v4f*>(out1 + row) = vk[q];
+                            if (out2) *reinterpret_cast<v4f*>(out2 + row) = vk[q] * s2 + t2;
                         }
                     }
                 }
+#ifdef FACEHIP_PW_ABL
+                if (i == 0 && j == 0) est3 = wall_clock64();                // first block's four stores issued
+#endif
             }
         }
+        };
+        with_act(p.act, [&](auto AC) {
+            if (p.res_mode != (int)ResMode::NONE) body(AC, ActC<1>{}); else body(AC, ActC<0>{});
+        });
+#ifdef FACEHIP_PW_ABL
+        if (threadIdx.x == 0 && p.slabs && p.Cout == 288 && p.Cin == 288) {   // (phase stamps of conv_pw_kernel, second half: see there)
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(p.slabs) + 8192 + (size_t)blockIdx.x * 4;
+            o[0] = est0; o[1] = est1; o[2] = wall_clock64();
+            unsigned long long* o2 = reinterpret_cast<unsigned long long*>(p.slabs) + 16384 + (size_t)blockIdx.x * 2;
+            o2[0] = est2; o2[1] = est3;
+        }
+#endif
         return;
     }
     if (ep && vec) {
         // per 32-pixel row block: its TN*4 residual float4s first, then per accumulator quad vectors from LDS, arithmetic, stores
         // (all TM row blocks' residuals up front would not fit the register file of the large tiles)
+        with_act(p.act, [&](auto AC) {
+        constexpr int A = decltype(AC)::value;
 #pragma unroll
         for (int i = 0; i < TL::TM; ++i) {
             const int m = m0 + (wm * TL::TM + i) * 32 + fr;
@@ -232,10 +300,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
                     if (co >= p.Cout) continue;
                     const v4f b4 = *reinterpret_cast<const v4f*>(ep + cls * BN + cl + 8 * g);
                     v4f sl = {0.f, 0.f, 0.f, 0.f};
-                    if (p.act == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(ep + 9 * BN + cl + 8 * g);
+                    if constexpr (A == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(ep + 9 * BN + cl + 8 * g);
                     v4f v;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) v[c] = apply_act(acc[i][j][4 * g + c] + b4[c], p.act, sl[c]);
+                    for (int c = 0; c < 4; ++c) v[c] = act_c<A>(acc[i][j][4 * g + c] + b4[c], sl[c]);
                     if (p.res_mode != (int)ResMode::NONE) v += r4[j][g];
                     if (out1) *reinterpret_cast<v4f*>(out1 + row + co) = v;
                     if (out2) {
@@ -245,6 +313,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
                 }
             }
         }
+        });
         return;
     }
 #pragma unroll
@@ -925,6 +994,51 @@ __global__ __launch_bounds__(256, OCC) void conv_pw_kernel(const ConvArgs p, con
         epv[k] = v;
     }
 
+#ifdef FACEHIP_PW_ABL
+    // Diagnostic build (scripts/pw_ablate.sh, scripts/pw_phases.py; an ablated run's results are garbage).  p.sk_test_drop bits: 1 = no loads
+    // in the K loop, 2 = no LDS reads, 4 = no barriers in the K loop, 8 = no epilogue, 16 = epilogue stores from one lane only,
+    // 32 = the CU's second workgroup starts (bits 8..) x 0.64 us late, 64 = wait for the stores' acknowledgement before the last stamp.
+    // Phase stamps (100 MHz ticks) of the 20x20x288 layers go to the stream-K workspace: [workgroup][entry, first chunk landed, K loop
+    // done, epilogue done] and, from 8192 on, [workgroup][epilogue entry, first block in LDS, last store issued, ep vectors parked].
+    const int abl = p.sk_test_drop;
+    const unsigned long long ts0 = wall_clock64();
+    if ((abl & 32) && blockIdx.x >= 256u && blockIdx.x < 512u)
+        while (wall_clock64() - ts0 < (unsigned long long)(abl >> 8) * 64ull) __builtin_amdgcn_s_sleep(32);
+    load_chunk(0);
+    __syncthreads();
+    const unsigned long long ts1 = wall_clock64();
+    v4f xk = lds[0][(wid * 32 + fr) * 8 + (fh2 ^ fsw)], wk[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) wk[j] = lds[0][BM * 8 + fr * 8 + j * 32 * 8 + (fh2 ^ fsw)];
+    for (int kc = 0; kc < chunks; ++kc) {
+        const int buf = (abl & 1) ? 0 : (kc & 1);
+        if (!(abl & 1) && kc + 1 < chunks) load_chunk(buf ^ 1);
+        const v4f* X = lds[buf] + (wid * 32 + fr) * 8;
+        const v4f* Wt = lds[buf] + BM * 8 + fr * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int col = (2 * s + fh2) ^ fsw;
+            v4f xv = xk;
+            v4f w[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) w[j] = wk[j];
+            if (!(abl & 2)) {
+                xv = X[col];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) w[j] = Wt[j * 32 * 8 + col];
+            }
+            asm volatile("" : "+v"(xv));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j][e], xv[e], acc[0][j], 0, 0, 0);
+        }
+        if (!(abl & 4)) __syncthreads();
+    }
+    __syncthreads();
+    const unsigned long long ts2 = wall_clock64();
+    if ((abl & 8) && acc[0][0][0] != 123.456f) return;
+#else
     load_chunk(0);
     __syncthreads();
     for (int kc = 0; kc < chunks; ++kc) {
@@ -946,6 +1060,7 @@ __global__ __launch_bounds__(256, OCC) void conv_pw_kernel(const ConvArgs p, con
         }
         __syncthreads();
     }
+#endif
     float* const ep = reinterpret_cast<float*>(&lds[0][0]);
 #pragma unroll
     for (int k = 0; k < EPN; ++k) {
@@ -954,7 +1069,19 @@ __global__ __launch_bounds__(256, OCC) void conv_pw_kernel(const ConvArgs p, con
     }
     __syncthreads();
     static_assert((12 * BN + 4 * 32 * 36) * sizeof(float) <= sizeof(lds), "epilogue scratch");
+#ifdef FACEHIP_PW_ABL
+    const bool stamp = tid == 0 && p.slabs && p.Cout == 288 && p.Cin == 288;
+    if (stamp) reinterpret_cast<unsigned long long*>(p.slabs)[8192 + (size_t)blockIdx.x * 4 + 3] = wall_clock64();
+#endif
     conv_epilogue<BM, BN, 4, 1>(p, acc, m0, n0, wid, 0, lane, -1, -1, ep, conv_ep_lines(p) ? ep + 12 * BN : nullptr);
+#ifdef FACEHIP_PW_ABL
+    if (stamp) {
+        const unsigned long long ts3 = wall_clock64();                  // stores issued
+        if (abl & 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and acknowledged
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.slabs) + (size_t)blockIdx.x * 5;
+        o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = (abl & 64) ? (unsigned long long)wall_clock64() : ts3; o[4] = 1;
+    }
+#endif
 }
 
 template <int BN, int OCC>
@@ -980,6 +1107,9 @@ static bool launch_pw(ConvArgs a, hipStream_t s) {
         return false;
     a.zeros = conv_zero_line();
     a.ep_direct = ep_direct_env();
+#ifdef FACEHIP_PW_ABL
+    { static const int abl = [] { const char* e = getenv("FACEHIP_PW_ABL"); return e ? atoi(e) : 0; }(); a.sk_test_drop = abl; }
+#endif
     const int cus = a.cus > 0 ? a.cus : conv_num_cus();
     auto cols = [&](int bn) { return (a.Cout + bn - 1) / bn * bn; };
     // widest tile whose padded columns cost <= 7 %; the 32-wide one otherwise (the generic kernel pads the same way)
