@@ -97,7 +97,15 @@ PROTOTYPES = {
     "fh_gallery_label_dev": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp]),
     "fh_gallery_topk_dev": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "fh_topk_merge_dev": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "fh_comm_unique_id": (_i, [_vp]),
+    "fh_comm_create": (_vp, [_i, _i, _vp, _i]),
+    "fh_comm_destroy": (None, [_vp]),
+    "fh_comm_rank": (_i, [_vp]),
+    "fh_comm_world": (_i, [_vp]),
+    "fh_comm_allgather_f32_dev": (_i, [_vp, _vp, _vp, _ll, _vp]),
+    "fh_gallery_topk_sharded_dev": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "fh_timing_enable": (_i, [_i]),
+    "fh_timing_num_tags": (_i, []),
     "fh_timing_collect": (_i, [_vp, _vp, _vp, _vp, _i]),
     "fh_timing_collect_ops": (_i, [_vp, _vp, _vp, _i]),
     "fh_det_set_conv_cfg": (_i, [_vp, _i, _i]),

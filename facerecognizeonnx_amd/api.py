@@ -297,6 +297,48 @@ class Gallery:
         check(_lib.lib().fh_gallery_label_dev(self._h, q_ptr, nq, threshold, labels_ptr, scores_ptr, stream), "fh_gallery_label_dev")
 
 
+class Comm:
+    """RCCL communicator behind the C ABI (fh_comm_*): one per process / rank.  `Comm.unique_id()` on rank 0, hand the 128 bytes to
+    the other ranks (torch.distributed's store, MPI, a file), then `Comm(rank, world, id, device)` on every rank."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_ubyte * 128)()
+        check(_lib.lib().fh_comm_unique_id(C.cast(buf, C.c_void_p)), "fh_comm_unique_id")
+        return bytes(buf)
+
+    def __init__(self, rank: int, world: int, uid: bytes, device: int = 0):
+        if len(uid) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        self._id = (C.c_ubyte * 128).from_buffer_copy(uid)
+        self._h = _lib.lib().fh_comm_create(rank, world, C.cast(self._id, C.c_void_p), device)
+        if not self._h:
+            raise _lib.FaceHipError("fh_comm_create failed: " + _lib.last_error())
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().fh_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def allgather_f32_dev(self, send_ptr: int, recv_ptr: int, count: int, stream: int = 0) -> int:
+        return check(_lib.lib().fh_comm_allgather_f32_dev(self._h, send_ptr, recv_ptr, count, stream), "fh_comm_allgather_f32_dev")
+
+    def gallery_topk_sharded_dev(self, gallery: "Gallery", q_ptr: int, nq_local: int, k: int, scores_ptr: int, idx_ptr: int,
+                                 stream: int = 0) -> int:
+        """queries all-gather -> local shard scan -> one top-k all-gather -> merge, all on `stream` (fh_gallery_topk_sharded_dev);
+        scores / indices = [world * nq_local][k] on every rank."""
+        return check(_lib.lib().fh_gallery_topk_sharded_dev(gallery._h, self._h, q_ptr, nq_local, k, scores_ptr, idx_ptr, stream),
+                     "fh_gallery_topk_sharded_dev")
+
+
 def plan_describe(path: str, default_h: int, default_w: int) -> str:
     buf = C.create_string_buffer(1 << 18)
     check(_lib.lib().fh_plan_describe(str(path).encode(), default_h, default_w, buf, len(buf)), "fh_plan_describe")

@@ -678,8 +678,9 @@ int fh_topk_merge_dev(const float* ps, const int* pi, int nparts, int nq, int k,
 
 // ---------------------------------------------------------------------------------- timing / tuning
 int fh_timing_enable(int on) { fh::KernelTimer::get().enabled = on != 0; return FH_OK; }
+int fh_timing_num_tags(void) { return fh::KernelTimer::kTags; }
 int fh_timing_collect(double* ms, double* flops, double* bytes, long long* launches, int n) {
-    if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need 13-entry arrays");
+    if (!ms || !flops || !bytes || !launches || n < fh::KernelTimer::kTags) return arg_error("fh_timing_collect: need fh_timing_num_tags()-entry arrays");
     return guarded([&] { fh::KernelTimer::get().collect(ms, flops, bytes, launches); return fh::KernelTimer::kTags; });
 }
 int fh_timing_collect_ops(double* ms, double* flops, int* tag, int cap) {
@@ -883,3 +884,7 @@ int fh_conv_forward_dev(const float* in, const float* wt, const float* bias, flo
 }
 
 }  // extern "C"
+
+namespace fh {
+Gallery& gallery_of(fh_gallery* g) { return g->g; }      // (comm.cpp: the sharded top-k works on the same object)
+}

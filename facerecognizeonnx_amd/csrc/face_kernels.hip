@@ -474,7 +474,7 @@ __device__ __forceinline__ bool better(float s1, int i1, float s2, int i2) { ret
 // a wave reduction + one LDS hand-off between the four waves; otherwise each round re-reads the lists from memory (L2).
 template <bool CACHED>
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ ps, const int* __restrict__ pi, int nparts, int Q, int k,
-                                                         float* __restrict__ out_s, int* __restrict__ out_i) {
+                                                         long part_stride, float* __restrict__ out_s, int* __restrict__ out_i) {
     __shared__ float rs[256];
     __shared__ int ri[256];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
             es[j] = -INFINITY; ei[j] = -1;
             if (e < total) {
                 const int part = e / k, pos = e - part * k;
-                const size_t o = ((size_t)part * Q + q) * k + pos;
+                const size_t o = (size_t)part * part_stride + (size_t)q * k + pos;
                 es[j] = ps[o]; ei[j] = pi[o];
             }
         }
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict
         } else {
             for (int e = tid; e < total; e += 256) {
                 const int part = e / k, pos = e - part * k;
-                const size_t o = ((size_t)part * Q + q) * k + pos;
+                const size_t o = (size_t)part * part_stride + (size_t)q * k + pos;
                 const float sc = ps[o]; const int gi = pi[o];
                 if (gi < 0 || exhausted) continue;
                 if (have_last && !better(last_s, last_i, sc, gi)) continue;     // must come strictly after the last pick
@@ -555,10 +555,16 @@ void launch_label(const float* best_score, const int* best_idx, int n, float thr
     if (n > 0) hipLaunchKernelGGL(label_kernel, dim3((n + 255) / 256), dim3(256), 0, s, best_score, best_idx, n, thr, labels);
 }
 
+// part_stride = words between the lists of consecutive parts (Q * k when they are packed; the sharded exchange of comm.cpp interleaves
+// score and index planes per rank)
+void launch_topk_merge_strided(const float* part_score, const int* part_idx, int nparts, int Q, int k, long part_stride, float* out_score,
+                               int* out_idx, hipStream_t s) {
+    if ((long)nparts * k <= 8192) hipLaunchKernelGGL(topk_merge_kernel<true>, dim3(Q), dim3(256), 0, s, part_score, part_idx, nparts, Q, k, part_stride, out_score, out_idx);
+    else hipLaunchKernelGGL(topk_merge_kernel<false>, dim3(Q), dim3(256), 0, s, part_score, part_idx, nparts, Q, k, part_stride, out_score, out_idx);
+}
 void launch_topk_merge(const float* part_score, const int* part_idx, int nparts, int Q, int k, float* out_score, int* out_idx,
                        hipStream_t s) {
-    if ((long)nparts * k <= 8192) hipLaunchKernelGGL(topk_merge_kernel<true>, dim3(Q), dim3(256), 0, s, part_score, part_idx, nparts, Q, k, out_score, out_idx);
-    else hipLaunchKernelGGL(topk_merge_kernel<false>, dim3(Q), dim3(256), 0, s, part_score, part_idx, nparts, Q, k, out_score, out_idx);
+    launch_topk_merge_strided(part_score, part_idx, nparts, Q, k, (long)Q * k, out_score, out_idx, s);
 }
 
 // ------------------------------------------------------------------------------------------

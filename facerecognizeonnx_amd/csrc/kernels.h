@@ -267,6 +267,8 @@ void launch_gallery_topk(const float* gal, long G, int dim, const float* qpacked
 void launch_label(const float* best_score, const int* best_idx, int n, float thr, int* labels, hipStream_t s);
 void launch_topk_merge(const float* part_score, const int* part_idx, int nparts, int Q, int k, float* out_score,
                        int* out_idx, hipStream_t s);
+void launch_topk_merge_strided(const float* part_score, const int* part_idx, int nparts, int Q, int k, long part_stride, float* out_score,
+                               int* out_idx, hipStream_t s);
 
 // detect -> embed hand-off: first min(count,F) faces per frame, densely packed (n <= 4096 frames)
 void launch_select_faces(const FaceRec* det, const int* counts, int n, int per_frame, int F, FaceRec* faces, int* frame_of,

@@ -171,6 +171,33 @@ FH_API int fh_gallery_topk_dev(fh_gallery* g, const float* d_queries, int nq, in
  * gallery returns exactly the single-gallery answer.  nparts * k <= 65536. */
 FH_API int fh_topk_merge_dev(const float* d_part_scores, const int* d_part_idx, int nparts, int nq, int k, float* d_scores,
                              int* d_indices, void* stream);
+/* ---- the exchange step of a row-sharded gallery behind the boundary (the reference's compareFaces loop,
+ * src/face_recognizer.cpp:320-334 / src/main.cpp:221-238, over a gallery split across the GPUs of one node).  One process (or
+ * thread) per rank; the collectives are RCCL (librccl, loaded on first use) on the CALLER's stream — no torch, no host copy.
+ *   fh_comm_unique_id   rank 0 fills a 128-byte id; the caller hands it to the other ranks (any side channel: MPI, a file,
+ *                       torch.distributed's store ...).
+ *   fh_comm_create      binds this process to `device` (hipSetDevice) and joins the communicator; collective over all ranks.
+ *                       Create it BEFORE the first fh_* object of the process where possible (RCCL sizes its buffers once).
+ *   fh_gallery_topk_sharded_dev
+ *                       every rank passes its nq_local query rows [nq_local][dim] (device) and its gallery shard `g` (uploaded
+ *                       with its global index base): all-gather of the queries -> scan of the local shard for all
+ *                       world * nq_local queries -> ONE all-gather of the per-rank (score, global index) lists -> merge
+ *                       (the kernel fh_gallery_topk_dev finishes with).  d_scores / d_indices = [world * nq_local][k] on EVERY
+ *                       rank, rank r's own queries in rows [r * nq_local, (r + 1) * nq_local): exactly the single-gallery
+ *                       answer (score desc, index asc).  All ranks must call it with the same nq_local and k.  Asynchronous
+ *                       on `stream`.  Returns world * nq_local, or < 0. */
+#define FH_COMM_ID_BYTES 128
+typedef struct fh_comm fh_comm;
+FH_API int fh_comm_unique_id(unsigned char id[FH_COMM_ID_BYTES]);
+FH_API fh_comm* fh_comm_create(int rank, int world, const unsigned char id[FH_COMM_ID_BYTES], int device);
+FH_API void fh_comm_destroy(fh_comm* c);
+FH_API int fh_comm_rank(const fh_comm* c);
+FH_API int fh_comm_world(const fh_comm* c);
+/* all-gather of equally sized float blocks on the caller's stream: d_recv = [world][count] (the frame-sharded callers use it for
+ * per-rank embeddings; the sharded top-k uses it internally) */
+FH_API int fh_comm_allgather_f32_dev(fh_comm* c, const float* d_send, float* d_recv, long long count, void* stream);
+FH_API int fh_gallery_topk_sharded_dev(fh_gallery* g, fh_comm* c, const float* d_queries_local, int nq_local, int k,
+                                       float* d_scores, int* d_indices, void* stream);
 /* The webcam loop's reference handling (src/main.cpp:211-212,229-233,253-256) for an enrolled SET instead of one
  * refFeature: enroll appends rows (the 's' key; returns the index of the first new row), label gives every query its
  * best row when (dot+1)/2 > threshold ("Match", reference threshold 0.6, strict) and -1 otherwise ("Unknown");
@@ -183,11 +210,13 @@ FH_API int fh_gallery_label_dev(fh_gallery* g, const float* d_queries, int nq, f
 /* ---- measurement hooks (bench.py): per-launch HIP-event timing of the network kernels.
  * Tags 0..3 = conv_igemm tile configs (128x128, 256x64, 128x32, 64x64), 4 = depthwise / depthwise+pointwise,
  * 5 = other graph ops, 6 = conv stream-K fix-up, 7 = Winograd GEMM (its FLOPs = executed; bytes slot = the layer's
- * direct-form FLOPs), 8 = Winograd transforms, 9 = spatial-tile (LDS halo) 3x3 convolutions, 10 = conv_tall_kernel (whole tile rounds of the 3x3 stride-1 layers), 11 = conv_pw_kernel (1x1 stride-1 convolutions as plain GEMMs).  fh_timing_collect synchronises, fills 12-entry arrays (elapsed ms,
+ * direct-form FLOPs), 8 = Winograd transforms, 9 = spatial-tile (LDS halo) 3x3 convolutions, 10 = conv_tall_kernel (whole tile rounds of the 3x3 stride-1 layers), 11 = conv_pw_kernel (1x1 stride-1 convolutions as plain GEMMs), 12 = wino2_kernel (fused Winograd F(2x2,3x3): FLOPs = executed, bytes slot = the
+ * layer's direct-form FLOPs).  fh_timing_num_tags() = 13 today; fh_timing_collect synchronises, fills n >= fh_timing_num_tags() entry arrays (elapsed ms,
  * algorithmic FLOP, algorithmic activation bytes, launches) and resets the counters.
  * fh_*_set_conv_cfg forces one tile config for every dense conv of a handle (-1 = automatic)
  * and switches the stream-K remainder wave on/off (tuning / A-B measurements). */
 FH_API int fh_timing_enable(int on);
+FH_API int fh_timing_num_tags(void);
 FH_API int fh_timing_collect(double* ms, double* flops, double* bytes, long long* launches, int n);
 FH_API int fh_timing_collect_ops(double* ms, double* flops, int* tag, int cap);   /* per launch, in order */
 FH_API int fh_det_set_conv_cfg(fh_det* d, int cfg, int stream_k);

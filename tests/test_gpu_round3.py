@@ -33,19 +33,9 @@ def _gpu():
 
 
 def _match_records(g, ref):
-    """Every oracle record must have a GPU counterpart: score 1e-4, box +-1 px (a 1e-6 network difference may flip an int
-    truncation, face_detector.cpp:255-265), landmarks 1e-2 px.  Returns (missing, surplus)."""
-    used = np.zeros(len(g), bool)
-    missing = 0
-    for r in ref:
-        near = np.where(~used & (np.abs(g["score"] - r["score"]) < 1e-4))[0]
-        ok = [j for j in near if max(abs(int(g[j][k]) - int(r[k])) for k in ("x", "y", "w", "h")) <= 1 and
-              np.abs(g[j]["lm"] - r["lm"]).max() < 1e-2]
-        if ok:
-            used[ok[0]] = True
-        else:
-            missing += 1
-    return missing, int((~used).sum())
+    """(missing, surplus) counts of tests.util.match_records: score 1e-4, box +-1 px, landmarks 1e-2 px."""
+    missing, surplus = util.match_records(g, ref)
+    return len(missing), len(surplus)
 
 
 @pytest.mark.timeout(600)

@@ -2,6 +2,7 @@
 include/facehip.h declares, the C++ ONNX reader + planner (no GPU calls), the reference-shaped
 error behaviour of the Python mirror classes, and the multi-rank host logic on gloo (world 2).
 """
+import ctypes
 import os
 import re
 import subprocess
@@ -177,6 +178,24 @@ def test_sharded_gallery_topk_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"rank {r} ok" in o, o
+
+
+def test_comm_boundary_loads_rccl_and_rejects_bad_arguments_without_a_gpu():
+    """The exchange step behind the C ABI (include/facehip.h fh_comm_*): librccl is dlopen'ed on first use, a unique id is 128 bytes
+    (ncclUniqueId) and differs per call; argument errors come back as NULL / FH_ERR_ARG with a message — no compute call is made
+    here (no GPU in this container)."""
+    ids = [fa.Comm.unique_id() for _ in range(2)]
+    assert all(len(i) == 128 for i in ids) and ids[0] != ids[1] and any(ids[0])
+    L = fa.lib()
+    buf = (ctypes.c_ubyte * 128).from_buffer_copy(ids[0])
+    for rank, world, dev in ((2, 2, 0), (-1, 1, 0), (0, 0, 0), (0, 1, -1)):
+        assert not L.fh_comm_create(rank, world, ctypes.cast(buf, ctypes.c_void_p), dev)
+        assert "bad argument" in _lib.last_error()
+    assert not L.fh_comm_create(0, 1, None, 0)
+    assert L.fh_comm_rank(None) == -1 and L.fh_comm_world(None) == -1          # FH_ERR_ARG
+    assert L.fh_gallery_topk_sharded_dev(None, None, None, 1, 1, None, None, None) == -1
+    assert L.fh_comm_allgather_f32_dev(None, None, None, 4, None) == -1
+    assert L.fh_timing_num_tags() == 13
 
 
 def _affine_graph(path, H=24, W=20, C=12, Cout=8):

@@ -77,3 +77,50 @@ def write_bmp(path, bgr):
         f.write(b"BM" + struct.pack("<IHHI", 54 + len(rows), 0, 0, 54))
         f.write(struct.pack("<IiiHHIIiiII", 40, w, h, 1, 24, 0, len(rows), 2835, 2835, 0, 0))
         f.write(rows)
+
+
+def match_records(got, ref, box_tol=1, lm_tol=1e-2, score_tol=1e-4):
+    """Pair EVERY record of `ref` (oracle) with one of `got` (GPU): score within `score_tol`, box within `box_tol` px (a 1e-6 network
+    difference may flip an int truncation, face_detector.cpp:255-265), landmarks within `lm_tol` px.  Returns the index lists
+    (unmatched ref, unmatched got)."""
+    used = np.zeros(len(got), bool)
+    missing = []
+    for i, r in enumerate(ref):
+        near = np.where(~used & (np.abs(got["score"] - r["score"]) < score_tol))[0]
+        ok = [j for j in near if max(abs(int(got[j][k]) - int(r[k])) for k in ("x", "y", "w", "h")) <= box_tol and
+              np.abs(got[j]["lm"] - r["lm"]).max() < lm_tol]
+        if ok:
+            used[ok[0]] = True
+        else:
+            missing.append(i)
+    return missing, [int(j) for j in np.where(~used)[0]]
+
+
+def _iou_int(a, b):
+    """FaceDetector::iou (face_detector.cpp:340-354): integer intersection, int denominator."""
+    x1 = max(int(a["x"]), int(b["x"])); y1 = max(int(a["y"]), int(b["y"]))
+    x2 = min(int(a["x"]) + int(a["w"]), int(b["x"]) + int(b["w"])); y2 = min(int(a["y"]) + int(a["h"]), int(b["y"]) + int(b["h"]))
+    inter = max(0, x2 - x1) * max(0, y2 - y1)
+    den = int(a["w"]) * int(a["h"]) + int(b["w"]) * int(b["h"]) - inter
+    return inter / den if den else float("nan")
+
+
+def assert_records_equivalent(got, ref, score_thr, nms_thr, box_tol=1, lm_tol=1e-2, max_unexplained=0):
+    """All records, not a prefix: every oracle record has a GPU counterpart and vice versa.  A record may be unmatched only where a
+    ~1e-6 difference of the network outputs can legitimately change the decision: its score lies within 1e-4 of the score threshold
+    (strict `>`, face_detector.cpp:253), or its integer IoU with a better-scored record of EITHER list lies within 0.02 of the NMS
+    threshold (a +-1 px truncation flip moves the IoU of a small box across the strict `>` of face_detector.cpp:369-371)."""
+    missing, surplus = match_records(got, ref, box_tol, lm_tol)
+    unexplained = []
+    both = list(got) + list(ref)
+    for side, idx, arr in (("ref", missing, ref), ("gpu", surplus, got)):
+        for i in idx:
+            r = arr[i]
+            if abs(float(r["score"]) - score_thr) < 1e-4:
+                continue
+            ious = [_iou_int(r, o) for o in both if float(o["score"]) >= float(r["score"]) - 1e-4]
+            if any(abs(v - nms_thr) < 0.02 for v in ious if v == v):
+                continue
+            unexplained.append((side, i, float(r["score"]), [int(r[k]) for k in ("x", "y", "w", "h")]))
+    assert len(unexplained) <= max_unexplained, (len(got), len(ref), unexplained[:8])
+    return len(missing), len(surplus)
