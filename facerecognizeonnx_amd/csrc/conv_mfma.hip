@@ -37,6 +37,8 @@
 // owners: every segment goes to a slab and conv_fixup_kernel sums them in a second launch.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -202,9 +204,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, v16f (&acc)[BM 
 #pragma unroll
                     for (int k = 0; k < 4; ++k) r4[k] = cok ? *reinterpret_cast<const v4f*>(res + res_row(min(mb + 8 * k, M - 1)) + co) : v4f{0.f, 0.f, 0.f, 0.f};
                 }
+                wave_lds_order();                                            // (the previous block's scratch reads lie above these writes)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
                     *reinterpret_cast<v4f*>(blk + fr * 36 + 8 * g + 4 * fh2) = v4f{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                wave_lds_order();                                            // (lane (rr, cq) reads rows other lanes wrote)
                 v4f sl = {0.f, 0.f, 0.f, 0.f}, s2 = sl, t2 = sl;
                 if constexpr (A == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(ep + 9 * BN + cl);
                 if (out2) { s2 = *reinterpret_cast<const v4f*>(ep + 10 * BN + cl); t2 = *reinterpret_cast<const v4f*>(ep + 11 * BN + cl); }
@@ -1166,7 +1170,7 @@ void conv_workspace_reset_async(float* ws, hipStream_t s) { (void)hipMemsetAsync
 
 // ---- stream-K watchdog: a host-mapped (pinned, device-visible) record an owner writes when its hand-off wait times out
 static unsigned* g_sk_err = nullptr;
-static unsigned g_sk_generation = 0;
+static std::atomic<unsigned> g_sk_generation{0};      // (handles may be driven from different host threads)
 static unsigned g_sk_timeout = (unsigned)((2000ull * 100000ull) >> 16);      // 2 s in units of 2^16 ticks of the 100 MHz wall clock
 static int g_sk_test_drop = 0;
 unsigned* conv_error_words() {
@@ -1208,14 +1212,14 @@ bool conv_take_error(std::string& msg, unsigned* rec) {
              "abandoned, its outputs are incomplete", e[1], e[2], e[3]);
     msg = buf;
     e[0] = 0;
-    ++g_sk_generation;                                   // every workspace's counters are suspect: owners re-zero them before their next run
+    g_sk_generation.fetch_add(1, std::memory_order_relaxed);                                   // every workspace's counters are suspect: owners re-zero them before their next run
     return true;
 }
-unsigned conv_error_generation() { return g_sk_generation; }
-static unsigned g_sk_debug_gen = 0;
-unsigned conv_debug_generation() { return g_sk_debug_gen; }
+unsigned conv_error_generation() { return g_sk_generation.load(std::memory_order_relaxed); }
+static std::atomic<unsigned> g_sk_debug_gen{0};
+unsigned conv_debug_generation() { return g_sk_debug_gen.load(std::memory_order_relaxed); }
 void conv_debug_streamk(int drop_publish, int timeout_ms) {
-    ++g_sk_debug_gen;
+    g_sk_debug_gen.fetch_add(1, std::memory_order_relaxed);
     g_sk_test_drop = drop_publish;
     g_sk_timeout = (unsigned)(((unsigned long long)(timeout_ms > 0 ? timeout_ms : 2000) * 100000ull) >> 16);
 }

@@ -330,6 +330,14 @@ void launch_cb(const ConvArgs& a, hipStream_t s) {
     const int tgy = ((a.H + 1) / 2 + 3) / 4, tgx = ((a.W + 1) / 2 + 3) / 4;
     const long n_tg = (long)a.B * tgy * tgx;
     const int tiles_n = (a.Cout + 16 * CB - 1) / (16 * CB);
+    // The kernel XORs swizzle keys into ABSOLUTE LDS addresses (rb[] ^ (j << 6)): that equals base + (offset ^ key) only while the dynamic
+    // LDS base is 256-byte aligned, i.e. 0 — true as long as the kernel declares no static __shared__ object.  Checked once per instantiation.
+    static const bool lds_ok = [] {
+        hipFuncAttributes fa{};
+        FH_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&wino2_kernel<CB>)));
+        return fa.sharedSizeBytes % 256 == 0;
+    }();
+    if (!lds_ok) throw std::runtime_error("wino2: static LDS moved the halo off its 256-byte alignment (see the address XOR in fetch_d)");
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
     hipLaunchKernelGGL((wino2_kernel<CB>), dim3((unsigned)(n_tg * tiles_n)), dim3(64), 25600, s, a, tiles_n, tgx, tgy, (int)n_tg);

@@ -328,7 +328,13 @@ Net::Net(const std::string& onnx_path, int default_h, int default_w) {
 
 Net::SkRecord::~SkRecord() {
     if (!p) return;
-    (void)hipDeviceSynchronize();                         // no launch of this Net can write the record once it is back on the free list
+    // no launch of this Net can write the record once it is back on the free list: drain the NET's device, which need not be the
+    // calling thread's current one (one handle per device, destroyed from any thread)
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (device >= 0 && device != cur) (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    if (device >= 0 && device != cur && cur >= 0) (void)hipSetDevice(cur);
     conv_error_record_release(p);
 }
 
@@ -339,7 +345,7 @@ void Net::reserve(int max_batch) {
     if (partial_.bytes < conv_slab_floats() * sizeof(float)) {
         partial_.ensure(conv_slab_floats() * sizeof(float));
         conv_workspace_init(partial_.as<float>());
-        if (!sk_rec_.p) sk_rec_.p = conv_error_record_new();
+        if (!sk_rec_.p) { sk_rec_.p = conv_error_record_new(); (void)hipGetDevice(&sk_rec_.device); }
         if (!sk_rec_.p) throw std::runtime_error("HIP error: cannot allocate the stream-K watchdog record");
         sk_gen_ = conv_error_generation();
     }

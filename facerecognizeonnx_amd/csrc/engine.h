@@ -109,6 +109,7 @@ class Net {
     int cap_ = 0;
     struct SkRecord {                                         // host-mapped; parked on a free list at destruction (the device may still write it)
         unsigned* p = nullptr;
+        int device = -1;                                      // the device whose launches write it (set with p)
         SkRecord() = default;
         SkRecord(const SkRecord&) = delete;
         SkRecord& operator=(const SkRecord&) = delete;

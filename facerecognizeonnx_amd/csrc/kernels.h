@@ -12,6 +12,19 @@ namespace fh {
 void hip_check(hipError_t e, const char* what);
 #define FH_HIP(x) ::fh::hip_check((x), #x)
 
+// Orders one wave's own LDS stores before its own later LDS loads of bytes OTHER lanes stored (the per-wave turn-around scratch of the
+// whole-line epilogues) and those loads before the next round's stores.  LDS operations of one wave execute in issue order, so no
+// instruction is needed; this only keeps the COMPILER from moving an access across one it cannot prove disjoint (wavefront-scope fence +
+// wave barrier: no code is emitted).
+#if defined(__HIPCC__)
+__device__ __forceinline__ void wave_lds_order() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+#endif
+
 // Optional per-launch HIP-event timing of the network kernels (bench.py's roofline leg).
 // Tags: 0..3 = conv_igemm tile configs, 4 = depthwise conv, 5 = other graph ops, 6 = conv stream-K fix-up.
 struct KernelTimer {

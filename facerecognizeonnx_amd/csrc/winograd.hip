@@ -353,6 +353,7 @@ __device__ __forceinline__ void wino_store_lines(const v16f (&acc)[TN], float* s
     const int rr = lane / (W / 4), cq = lane % (W / 4);
 #pragma unroll
     for (int h = 0; h < TN / JB; ++h) {
+        wave_lds_order();                                                   // (the previous half's scratch reads lie above these writes)
 #pragma unroll
         for (int jj = 0; jj < JB; ++jj)
 #pragma unroll
@@ -360,6 +361,7 @@ __device__ __forceinline__ void wino_store_lines(const v16f (&acc)[TN], float* s
                 const int j = h * JB + jj;
                 *reinterpret_cast<v4f*>(blk + fr * PITCH + jj * 32 + 8 * g + 4 * fh2) = v4f{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
             }
+        wave_lds_order();                                                   // (lane (rr, cq) reads rows other lanes wrote)
         float* const obase = M + (size_t)(m0 + wid * 32 + rr) * N + n0 + h * W + 4 * cq;
 #pragma unroll
         for (int i = 0; i < 32 / RPI; ++i)
