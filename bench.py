@@ -66,6 +66,10 @@ def parse():
     ap.add_argument("--gallery", type=int, default=0, help="config C4/C5: also match every embedding against a gallery of this many "
                     "512-d rows (row-sharded over the ranks; per-rank top-k all-gathered and merged)")
     ap.add_argument("--topk", type=int, default=16)
+    ap.add_argument("--exchange", default="auto", choices=["auto", "cabi", "torch"], help="--gallery with N > 1: where the two all-gathers of "
+                    "the sharded top-k run.  cabi = behind the C ABI (fh_comm_* over librccl, fh_gallery_topk_sharded_dev: queries "
+                    "all-gather -> scan -> one top-k all-gather -> merge, on the launch stream); torch = torch.distributed + "
+                    "fh_topk_merge_dev (the only form gloo rehearsals can take); auto = cabi on nccl, torch otherwise")
     ap.add_argument("--serial", action="store_true", help="e2e: one batch at a time on one stream (fh_pipeline_run_dev).  The default since "
                     "round 3 is the library's streaming form (fh_pipeline_submit_dev): the detector of batch k+1 runs on its own HIP stream "
                     "beside the recogniser of batch k (+4.4 %% measured); every batch is complete inside the timed region (device-wide "
@@ -459,7 +463,7 @@ def main():
                 return fa.pipeline_run_dev(det, rec, data.data_ptr(), B, 640, 640, F, faces.data_ptr(), frame_of.data_ptr(),
                                            emb.data_ptr(), args.score_thr, args.nms_thr, stream)
             step = step_serial
-        pipelined = args.workload == "e2e" and not args.serial and not args.from_host and not args.gallery
+        pipelined = args.workload == "e2e" and not args.serial and not args.from_host and not (args.gallery and world > 1)
         if pipelined:
             # Streaming form (fh_pipeline_submit_dev): the detector of batch k+1 is queued on its own HIP stream and
             # runs beside the recogniser of batch k (HBM-bound next to MFMA-bound work); no host sync per batch.
@@ -520,19 +524,54 @@ def main():
         k = args.topk
         sc = torch.zeros((nq * world, k), device="cuda"); ix = torch.zeros((nq * world, k), dtype=torch.int32, device="cuda")
         inner = step
+        exchange = args.exchange if args.exchange != "auto" else ("cabi" if args.dist_backend == "nccl" else "torch")
+        comm = None
+        if world > 1 and exchange == "cabi":
+            # the communicator behind the C ABI: rank 0's id travels through the process group that already exists
+            uid = [fa.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = fa.Comm(rank, world, uid[0], local)
 
-        def step():                                   # noqa: F811
-            n = inner()
-            if world > 1:                             # every rank scores ALL queries against its own gallery shard
-                q = fd.allgather_queries(emb.to(cdev)).to("cuda")
-            else:
-                q = emb
-            for off in range(0, q.shape[0], 256):
-                m = min(256, q.shape[0] - off)
-                gallery.topk_dev(q[off:off + m].data_ptr(), m, k, sc[off:off + m].data_ptr(), ix[off:off + m].data_ptr(), stream)
-            if world > 1:                             # ONE all-gather of the per-rank lists, merged by the library's kernel
-                fd.allgather_topk(sc, ix, k, comm_device=cdev)
-            return n
+        if locals().get("pipelined"):
+            # streaming form with the 1:N match: the scan of batch k is queued on the recogniser's stream right behind its embeddings
+            # (per-slot result buffers), so it runs beside the detector of batch k+1 like the rest of the recogniser's work
+            gsc = [torch.zeros((nq, k), device="cuda") for _ in range(RING)]
+            gix = [torch.zeros((nq, k), dtype=torch.int32, device="cuda") for _ in range(RING)]
+
+            def step():                               # noqa: F811
+                slot = state["k"] % RING
+                n = inner()
+                for off in range(0, nq, 256):
+                    m = min(256, nq - off)
+                    gallery.topk_dev(re_[slot][off:off + m].data_ptr(), m, k, gsc[slot][off:off + m].data_ptr(),
+                                     gix[slot][off:off + m].data_ptr(), s_rec.cuda_stream)
+                done[slot] = torch.cuda.Event(); done[slot].record(s_rec)      # the slot is free once its scan has read the embeddings
+                return n
+
+            serial_inner = step_serial
+
+            def step_serial():                        # noqa: F811
+                n = serial_inner()
+                for off in range(0, nq, 256):
+                    m = min(256, nq - off)
+                    gallery.topk_dev(emb[off:off + m].data_ptr(), m, k, sc[off:off + m].data_ptr(), ix[off:off + m].data_ptr(), stream)
+                return n
+        else:
+            def step():                               # noqa: F811
+                n = inner()
+                if comm is not None:                  # both all-gathers, the scan and the merge behind the boundary, on the launch stream
+                    comm.gallery_topk_sharded_dev(gallery, emb.data_ptr(), nq, k, sc.data_ptr(), ix.data_ptr(), stream)
+                    return n
+                if world > 1:                         # every rank scores ALL queries against its own gallery shard
+                    q = fd.allgather_queries(emb.to(cdev)).to("cuda")
+                else:
+                    q = emb
+                for off in range(0, q.shape[0], 256):
+                    m = min(256, q.shape[0] - off)
+                    gallery.topk_dev(q[off:off + m].data_ptr(), m, k, sc[off:off + m].data_ptr(), ix[off:off + m].data_ptr(), stream)
+                if world > 1:                         # ONE all-gather of the per-rank lists, merged by the library's kernel
+                    fd.allgather_topk(sc, ix, k, comm_device=cdev)
+                return n
 
     drain = locals().get("drain", lambda: 0)       # host-frame streaming form: retire the batches still in flight
     for _ in range(args.warmup):
@@ -632,7 +671,8 @@ def main():
                                           else "HBM-resident before the timed region",
                        "gallery_rows": args.gallery, "topk": args.topk if args.gallery else 0,
                        "parallelism": f"frame-sharded x{world}, " + ("gallery row-sharded, all-gather of queries + per-rank top-k"
-                                                                     if args.gallery and world > 1 else "no data-path collective")},
+                                                                     if args.gallery and world > 1 else "no data-path collective"),
+                       "exchange": (locals().get("exchange") if args.gallery and world > 1 else None)},
         }
         if timing:
             conv = [(ms[i], fl[i], ln[i], i) for i in (0, 1, 2, 3, 7, 9, 10, 11, 12) if ln[i] > 0]

@@ -315,6 +315,132 @@ __global__ __launch_bounds__(256, 2) void wino_fused_kernel(const WinoFuseArgs a
     }
 }
 
+// ---- the same fusion for maps of up to 56 tiles (28x28 = 49): one workgroup = ONE image x a 32-channel slice -------------------------
+// wino_fused_kernel's 16-channel slices (csl4 = 4) turn every activation access — residual, out1 / out2 — into 64-byte pieces, which is
+// why junctions that touch memory kept two separate kernels on these maps (116 us fused against 60 + 46 separate, 28x28x128 at B = 128).
+// With 32 channels a slice of a pixel is one whole 128-byte line, and the whole 28 x 28 slice (100 KB) still fits the CU's 160 KB of LDS:
+// thread = (tile, float4 column), 8 lanes per line, 7 waves per workgroup, one workgroup per CU.  LDS image [row][32 pixel slots][8 float4]:
+// the slot of column x has bits 0 and 2 of x exchanged, so that the two tiles of a ds_read_b128 lane group (x and x + 4) sit in opposite
+// halves of the 64 banks (a pixel's 128 bytes cover half of them) — without it every phase-2 read is a 2-way conflict.
+constexpr int kSliceThreads = 448, kSliceTiles = kSliceThreads / 8;
+__device__ __forceinline__ int wino_slice_slot(int x) { return (x & ~5) | ((x >> 2) & 1) | ((x & 1) << 2); }
+
+__global__ __launch_bounds__(kSliceThreads) void wino_slice_kernel(const WinoFuseArgs a) {
+    const WinoOutArgs& p = a.o;
+    extern __shared__ v4f act[];                               // [H][32 slots][8 float4]
+    const int C = p.C, TPI = p.TY * p.TX;
+    const int tid = threadIdx.x, c4l = tid & 7, tile = tid >> 3;
+    const int cslices = C >> 5;
+    // workgroups b, b + 8, b + 16 ... share an XCD (round-robin dispatch): the slices of one image go to ONE XCD, so that the 128-byte
+    // quarters of a 512-byte plane row are fetched by one L2 close together in time (speed only; any mapping is correct)
+    int blk = blockIdx.x;
+    if ((p.B & 7) == 0) { const int x = blk & 7, j = blk >> 3; blk = ((j / cslices) * 8 + x) * cslices + j % cslices; }
+    const int cs = blk % cslices, b = blk / cslices;
+    const int ty = tile / p.TX, tx = tile - ty * p.TX;
+    const bool live = tile < TPI;
+    const int c4 = cs * 8 + c4l;
+    const size_t fs = (size_t)p.NTp * C;
+    const bool slice_nt = a.img == 2;                          // (experiment switch FACEHIP_WINO_SLICE=2: M is read once and dead afterwards)
+    const size_t tg = ((size_t)b * p.TY + ty) * p.TX + tx;
+    if (live) {
+        // ---- phase 1: Y = A^T M A, epilogue, LDS image (every global access of the 8 lanes of a tile is one 128-byte line)
+        const float* src = p.M + tg * C + c4 * 4;
+        v4f t[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            v4f m[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = slice_nt ? __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + (size_t)(i * 6 + j) * fs)) : *reinterpret_cast<const v4f*>(src + (size_t)(i * 6 + j) * fs);
+            v4f y[4];
+            wino_at(m, y);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r][j] = y[r];
+        }
+        const v4f b4 = p.bias ? *reinterpret_cast<const v4f*>(p.bias + c4 * 4) : v4f{0.f, 0.f, 0.f, 0.f};
+        v4f rs[4][4];                                        // residual reads before the first store (see wino_output_kernel)
+        if (p.res) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int oy = 4 * ty + r, ox = 4 * tx + x;
+                    rs[r][x] = *reinterpret_cast<const v4f*>(p.res + (((size_t)b * p.H + min(oy, p.H - 1)) * p.W + min(ox, p.W - 1)) * C + c4 * 4);   // (clamped: unconditional)
+                }
+        }
+        v4f sl = {0.f, 0.f, 0.f, 0.f}, s2 = {1.f, 1.f, 1.f, 1.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+        if (p.act == (int)Act::PRELU) sl = *reinterpret_cast<const v4f*>(p.slope + c4 * 4);
+        if (p.s2) { s2 = *reinterpret_cast<const v4f*>(p.s2 + c4 * 4); t2 = *reinterpret_cast<const v4f*>(p.t2 + c4 * 4); }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oy = 4 * ty + r;
+            if (oy >= p.H) continue;
+            v4f y[4];
+            wino_at(t[r], y);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int ox = 4 * tx + x;
+                if (ox >= p.W) continue;
+                v4f v = y[x] + b4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float u = v[e];
+                    if (p.act == (int)Act::RELU) u = u > 0.f ? u : 0.f;
+                    else if (p.act == (int)Act::PRELU) u = u >= 0.f ? u : u * sl[e];
+                    else if (p.act == (int)Act::SIGMOID) u = 1.0f / (1.0f + expf(-u));
+                    v[e] = u;
+                }
+                const size_t o = (((size_t)b * p.H + oy) * p.W + ox) * C + c4 * 4;
+                if (p.res) v += rs[r][x];
+                if (p.out1) *reinterpret_cast<v4f*>(p.out1 + o) = v;
+                const v4f vb = v * s2 + t2;
+                if (p.out2) *reinterpret_cast<v4f*>(p.out2 + o) = vb;
+                act[(oy * 32 + wino_slice_slot(ox)) * 8 + c4l] = a.feed_aff ? vb : v;
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    // ---- phase 2: V = B^T d B from the LDS image (6x6 patch, rows / columns 4t-1 .. 4t+4, zeros outside the map)
+    const v4f* img = act + c4l;
+    const int iy0 = 4 * ty - 1, ix0 = 4 * tx - 1;
+    v4f tt[6][6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int ix = ix0 + c;
+        const int sx = wino_slice_slot(ix & 31);
+        v4f d[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int iy = iy0 + r;
+            const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            d[r] = ok ? img[(iy * 32 + sx) * 8] : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        v4f tc[6];
+        wino_bt(d, tc);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tt[i][c] = tc[i];
+    }
+    float* dst = a.V + tg * C + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        v4f o6[6];
+        wino_bt(tt[i], o6);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<v4f*>(dst + (size_t)(i * 6 + j) * fs) = a.pack ? wino_pack_bf16x2(o6[j]) : o6[j];
+    }
+}
+
+static int wino_slice_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("FACEHIP_WINO_SLICE"); v = e ? atoi(e) : 1; }          // (0: the round-4 behaviour, for A / B timing)
+    return v;
+}
+// maps of 17 .. 56 tiles whose 32-channel slice fits the LDS: W <= 32 (slot arithmetic), whole 32-channel slices
+static bool wino_slice_shape(int H, int W, int C) {
+    const int tpi = ((H + 3) / 4) * ((W + 3) / 4);
+    return wino_slice_enabled() && C % 32 == 0 && tpi > 16 && tpi <= kSliceTiles && W <= 32 && (size_t)H * 32 * 8 * sizeof(v4f) <= 160 * 1024;
+}
+
 // ---- the 36 GEMMs: M[f] = V[f] (rows x K) * U[f] (K x N), frequency planes stacked along the rows --------------------------
 // Same tile anatomy as conv_igemm_kernel (LDS-DMA with source-side swizzle, [row][32 k] LDS images, one ds_read_b128 per 4 MFMAs,
 // weights as the MFMA A operand) but nothing else: rows are contiguous, K and N are multiples of 32, the row count a multiple of
@@ -591,6 +717,20 @@ static bool wino_bn128(bool mixed) {
     return v == 2 || (v == 1 && mixed);
 }
 
+// 128x128 or 128x64 tiles for this launch?  The launch runs in whole ROUNDS of resident workgroups (2 per CU for the wide tile, 3 for the
+// narrow one) and every tile of a round takes the same time, so the cost of a shape is rounds x tiles-per-CU x work-per-tile — in units of
+// one 128x64 tile: 4 per round (wide) against 3 (narrow).  At B = 128 the two are level and the preference above decides (14x14x256: 968 wide
+// tiles = 2 rounds = 8 units against 1 936 narrow = 3 rounds = 9); at B = 64 the wide tiles spill 72 of 584 into a second, nearly empty
+// round (8 units against 6: 57 us per layer where half of the B = 128 time would be 37).
+static bool wino_pick_bn128(long row_tiles, int Cout, bool mixed, int cus) {
+    static const int force = [] { const char* e = getenv("FACEHIP_WINO_BN128"); return e ? atoi(e) : -1; }();
+    if (force >= 0) return wino_bn128(mixed);
+    const long cu = cus > 0 ? cus : 256;
+    const long wide = (row_tiles * (Cout / 128) + 2 * cu - 1) / (2 * cu) * 4, narrow = (row_tiles * (Cout / 64) + 3 * cu - 1) / (3 * cu) * 3;
+    if (wide != narrow) return wide < narrow;
+    return wino_bn128(mixed);
+}
+
 bool wino_mix_layout(int B, int H, int W, int Cin, int Cout, WinoPlanes* out) {
     const int TY = (H + 3) / 4, TX = (W + 3) / 4;
     const int my = (H & 3) == 1 || (H & 3) == 2, mx = (W & 3) == 1 || (W & 3) == 2;
@@ -651,7 +791,7 @@ void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, floa
             if (!wino_gemm_ok_bf16x2(a.Cin, a.Cout)) throw std::runtime_error("winograd: this layer has no split-bf16 GEMM");
             hipLaunchKernelGGL((wino_gemm_bf16x2_kernel<64, 3>), dim3((unsigned)((rows / 128) * (a.Cout / 64))), dim3(256), 0, s, V, wt36, M, a.Cin,
                                a.Cout, pl, g.wt_gs, a.Cout / 64, chunks);
-        } else if (wide && a.Cout % 128 == 0 && wino_bn128(mix != nullptr))
+        } else if (wide && a.Cout % 128 == 0 && wino_pick_bn128(rows / 128, a.Cout, mix != nullptr, a.cus))
             hipLaunchKernelGGL((wino_gemm_kernel<128, 2>), dim3((unsigned)((rows / 128) * (a.Cout / 128))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
                                pl, g.wt_gs, a.Cout / 128, chunks);
         else if (wide) {
@@ -711,6 +851,7 @@ static bool wino_fuse_shape(int H, int W, int C, int* csl4, int* pitch, int* img
 // slices, i.e. 64-byte pieces of every pixel row: fine for the M / V planes, but it halves the efficiency of those activation accesses
 // (28x28x128, B = 128: 116 us fused against 60 + 46 us separate) — such junctions keep the two separate kernels.
 bool wino_can_fuse(int H, int W, int C, bool touches_memory) {
+    if (wino_slice_shape(H, W, C)) return true;                // 32-channel slices: whole lines either way
     int csl4 = 0, pitch = 0, img = 0;
     if (!wino_fuse_shape(H, W, C, &csl4, &pitch, &img)) return false;
     return csl4 == 16 || !touches_memory;
@@ -720,6 +861,23 @@ bool wino_can_fuse(int H, int W, int C, bool touches_memory) {
 // which sees out1 (feed_aff = 0) or out1 * s2 + t2 (feed_aff = 1; a.s2 / a.t2 must then be set even when a.out2 is null).
 void launch_wino_fused(const ConvArgs& a, const float* M, float* Vnext, int feed_aff, bool pack_next, hipStream_t s) {
     WinoFuseArgs f{};
+    if (wino_slice_shape(a.H, a.W, a.Cout)) {
+        f.o = wino_out_args(a, M);
+        f.V = Vnext; f.feed_aff = feed_aff; f.pack = pack_next ? 1 : 0; f.csl4 = 8; f.pitch = 8; f.img = wino_slice_enabled() == 2 ? 2 : 1;
+        if (a.B <= 0) return;
+        wino_check((long)a.B * f.o.TY * f.o.TX, a.Cout);
+        const size_t lds = (size_t)a.H * 32 * 8 * sizeof(v4f);
+        static const bool attr = [] {                          // > 64 KB of dynamic LDS must be asked for once
+            FH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            return true;
+        }();
+        (void)attr;
+        KernelTimer& timer = KernelTimer::get();
+        timer.begin(s);
+        hipLaunchKernelGGL(wino_slice_kernel, dim3((unsigned)(a.B * (a.Cout / 32))), dim3(kSliceThreads), lds, s, f);
+        timer.end(s, 8, 0.0, 0.0);
+        return;
+    }
     if (!wino_fuse_shape(a.H, a.W, a.Cout, &f.csl4, &f.pitch, &f.img)) throw std::runtime_error("winograd: this map cannot take the fused transform");
     f.o = wino_out_args(a, M);
     f.V = Vnext; f.feed_aff = feed_aff; f.pack = pack_next ? 1 : 0;

@@ -216,3 +216,32 @@ def test_sharded_gallery_exchange_behind_the_c_abi_world1(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     p = subprocess.run([sys.executable, str(script), ROOT], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=560)
     assert p.returncode == 0 and "comm ok" in p.stdout, p.stdout[-3000:]
+
+
+@pytest.mark.timeout(600)
+def test_channel_sliced_fused_transform_on_28x28_maps_matches_oracle_and_unfused(tmp_path, monkeypatch):
+    """Between two Winograd layers on a 28 x 28 map (49 tiles) the output transform of the first and the input transform of the second
+    run as ONE kernel per (image, 32-channel slice) with the whole slice in LDS (winograd.hip `wino_slice_kernel`) — also at junctions
+    that read a residual and write out1 / out2.  An IResNet whose stage 2 is 28 x 28 x 128 (three blocks: conv -> PReLU -> conv junctions
+    without memory traffic, conv -> +residual -> BN -> conv junctions with it), batch 24 (>= 256 tiles per GEMM: Winograd form):
+    raw outputs against the oracle's direct fp32 evaluation (the stand-in for ORT's Run, face_recognizer.cpp:279-283) and to 1e-5 of
+    scale against the same handle with the fusion switched off (`fh_rec_set_wino_fusion(0)`: separate transform kernels — the same
+    arithmetic, but the compiler contracts multiply-adds per kernel, so not bit for bit)."""
+    path = models.make_iresnet(str(tmp_path / "s28.onnx"), (1, 3, 1, 1), (32, 128, 128, 128), 112, 64, seed=21)
+    desc = fa.plan_describe(path, 112, 112)
+    assert desc.count("k3s1 28x28x128 -> 28x28x128") >= 5, desc
+    rec = fa.FaceRecognizer(); orec = oracle.OracleRecognizer()
+    assert rec.loadModel(path) and orec.loadModel(path)
+    n = 24
+    crops = util.frames_u8(n, 112, 112, seed=77)
+    outs = []
+    for fuse in (1, 0):
+        assert fa.lib().fh_rec_set_wino_fusion(rec.handle, fuse) == 0
+        out = torch.zeros((n, 64), device="cuda"); raw = torch.zeros((n, 64), device="cuda")
+        assert rec.embed_aligned_dev(dev(crops).data_ptr(), n, out.data_ptr(), raw.data_ptr()) == n
+        torch.cuda.synchronize()
+        outs.append(raw.cpu().numpy())
+    assert np.abs(outs[0] - outs[1]).max() <= 1e-5 * np.abs(outs[1]).max(), np.abs(outs[0] - outs[1]).max()
+    for i in (0, n // 2, n - 1):
+        r = oracle.run_graph(orec.g, {orec.g.inputs[0][0]: oracle.rec_preprocess(crops[i])[None]})[orec.g.outputs[0][0]].reshape(-1)
+        np.testing.assert_allclose(outs[0][i], r, rtol=2e-4, atol=2e-4 * np.abs(r).max(), err_msg=f"slot {i}")
