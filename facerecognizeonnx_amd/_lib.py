@@ -138,6 +138,7 @@ PROTOTYPES = {
     "fh_conv_winograd_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "fh_debug_wino2_clock_mhz": (_d, []),
     "fh_conv_wino2_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "fh_conv_wino2_ex_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "fh_conv_wt_rows": (_i, [_i]),
     "fh_conv_pack_weights": (_i, [_vp, _i, _i, _i, _vp]),
     "fh_conv_kpad": (_i, [_i]),

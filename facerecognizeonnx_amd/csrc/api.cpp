@@ -820,24 +820,39 @@ int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi, const float* d_
 }
 // Fused Winograd F(2x2,3x3) form (conv_wino2.hip) of one 3x3 stride-1 pad-1 convolution, for the parity tests: w_ohwi = host weights
 // [cout][3*3][cin]; d_bias [cout] or, with bias_cls, [9][cout]; act = fh::Act; d_slope / d_res optional
-int fh_conv_wino2_dev(const float* d_in, const float* w_ohwi, const float* d_bias, const float* d_slope, const float* d_res, float* d_out,
-                      int batch, int h, int w, int cin, int cout, int act, int bias_cls, void* stream) {
-    if (!d_in || !w_ohwi || !d_out || cin != 64 || cout % 64) return arg_error("fh_conv_wino2_dev: bad argument (cin = 64, cout % 64 == 0)");
+int fh_conv_wino2_ex_dev(const float* d_in, const float* w_ohwi, const float* d_bias, const float* d_slope, const float* d_res, float* d_out,
+                         float* d_out2, const float* d_s2, const float* d_t2, int n_outs, float* const* d_outs, const int* oc0, const int* oact,
+                         int batch, int h, int w, int cin, int cout, int act, int bias_cls, void* stream) {
+    if (!d_in || !w_ohwi || batch <= 0 || h <= 0 || w <= 0 || cin != 64 || cout <= 0) return arg_error("fh_conv_wino2_dev: bad argument (cin = 64, positive sizes)");
+    if (n_outs < 0 || n_outs > 3 || (n_outs > 0 && (!d_outs || !oc0 || !oact))) return arg_error("fh_conv_wino2_dev: bad merged-output description");
+    if (n_outs == 0 && ((!d_out && !d_out2) || cout % 64)) return arg_error("fh_conv_wino2_dev: plain layers need an output and cout % 64 == 0");
+    if (d_out2 && (!d_s2 || !d_t2)) return arg_error("fh_conv_wino2_dev: a second output needs its scale and shift");
+    Owns owns(nullptr);                                                  // (no Net: the process-wide watchdog record)
     return guarded([&] {
+        fh::ConvArgs a{};
+        a.in = d_in; a.bias = d_bias; a.slope = d_slope; a.res = d_res; a.out1 = d_out; a.out2 = d_out2; a.s2 = d_s2; a.t2 = d_t2;
+        a.B = batch; a.H = h; a.W = w; a.Ho = h; a.Wo = w; a.Cin = cin; a.Cout = cout; a.ks = 3; a.stride = 1; a.pad = 1;
+        a.act = act; a.bias_cls = bias_cls; a.res_mode = d_res ? (int)fh::ResMode::SAME : (int)fh::ResMode::NONE;
+        a.n_outs = n_outs;
+        for (int g = 0; g < n_outs; ++g) { a.outs[g] = d_outs[g]; a.oact[g] = oact[g]; a.oc0[g] = oc0[g]; }
+        if (n_outs > 0) a.oc0[n_outs] = oc0[n_outs];
+        if (!fh::wino2_ok(a)) throw std::runtime_error("fh_conv_wino2_dev: layer shape not supported by the fused F(2x2) kernel");
         std::vector<float> u(fh::wino2_weight_floats(cin, cout));
         fh::wino2_pack_weights(w_ohwi, cout, cin, u.data());
         fh::DevBuf dU;
         dU.ensure(u.size() * sizeof(float));
         FH_HIP(hipMemcpy(dU.p, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
-        fh::ConvArgs a{};
-        a.in = d_in; a.wt = dU.as<float>(); a.bias = d_bias; a.slope = d_slope; a.res = d_res; a.out1 = d_out;
-        a.B = batch; a.H = h; a.W = w; a.Ho = h; a.Wo = w; a.Cin = cin; a.Cout = cout; a.ks = 3; a.stride = 1; a.pad = 1;
-        a.act = act; a.bias_cls = bias_cls; a.res_mode = d_res ? (int)fh::ResMode::SAME : (int)fh::ResMode::NONE;
+        a.wt = dU.as<float>();
         fh::launch_wino2(a, S(stream));
         FH_HIP(hipGetLastError());
         FH_HIP(hipStreamSynchronize(S(stream)));                 // the weight image dies with this scope
         return 0;
     });
+}
+int fh_conv_wino2_dev(const float* d_in, const float* w_ohwi, const float* d_bias, const float* d_slope, const float* d_res, float* d_out,
+                      int batch, int h, int w, int cin, int cout, int act, int bias_cls, void* stream) {
+    return fh_conv_wino2_ex_dev(d_in, w_ohwi, d_bias, d_slope, d_res, d_out, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, batch, h, w,
+                                cin, cout, act, bias_cls, stream);
 }
 double fh_debug_wino2_clock_mhz(void) { return fh::wino2_debug_clock_mhz(); }
 int fh_conv_wt_rows(int cout) { return fh::conv_wt_rows(cout); }

@@ -76,11 +76,17 @@ template <int V> struct IC { static constexpr int value = V; };          // comp
                                                                           // 16 instantiations (`#pragma unroll` gives up on a body of this size, and a
                                                                           // run-time f turns every B^T / A^T coefficient into a branch)
 
-template <int CB>
-__global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const int tiles_n, const int tgx, const int tgy, const int n_tg) {
+// NW = waves per workgroup that share ONE halo: wave w computes the 16 CB channels [16 CB w, 16 CB (w + 1)) of the workgroup's 16 CB NW-channel
+// column tile (NW = 1: the original one-wave form).  MERGED selects the merged-sibling epilogue (per-channel-range destinations).
+// NW = 2, CB = 2 on the plain 64-channel layers: the 25.6 KB halo limits a CU to six workgroups either way, so six waves of 226 registers
+// (1.5 per SIMD: two SIMDs carry two waves, two carry one) become twelve of 112 (three per SIMD) — see DESIGN.md.
+template <int CB, int NW, bool MERGED>
+__global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 3) void wino2_kernel(const ConvArgs p, const int tiles_n, const int tgx, const int tgy, const int n_tg) {
     extern __shared__ v4f w2sm[];
     char* const halo = reinterpret_cast<char*>(w2sm);                      // [5][5] plane pixels x [4 parity planes] x 16 x 16 B
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    constexpr int CBT = CB * NW;                                           // 16-channel blocks per column tile in the weight image
 #ifdef FACEHIP_W2_PROF
     const long long prof_c0 = __builtin_readcyclecounter(), prof_r0 = __builtin_amdgcn_s_memrealtime();   // shader clock vs the constant 100 MHz counter
 #endif
@@ -110,6 +116,7 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
             const int pr = i / 5, pc = i - 5 * pr;
             const int y = y0 + 2 * pr, x = x0 + 2 * pc;
             const bool ok = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            if (NW > 1 && (i % NW) != wv) continue;                        // (wave-uniform: the waves of a workgroup take alternate pieces)
             dma16(ok ? img + ((long)2 * pr * W + 2 * pc) * 64 + ((col ^ key(pr, pc)) << 2) : p.zeros, halo + i * 1024);
         }
     }
@@ -126,7 +133,7 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
     // weights of this column tile: step (f, j) = CB KB at ((f * 4 + j) * CB) * 256 floats; cb-th fragment + cb * 256
     // (a wave-uniform running pointer + the lane's 16-byte offset: with compile-time step offsets the 64 step addresses are hoisted out of
     //  the loop into 128 registers)
-    const char* wstep = reinterpret_cast<const char*>(p.wt + (size_t)tile_n * 64 * CB * 256);
+    const char* wstep = reinterpret_cast<const char*>(p.wt + ((size_t)tile_n * 64 * CBT + (size_t)wv * CB) * 256);
     const unsigned wlane = lane * 16;
     constexpr int WD = 2;                                                  // weight ring: fragments are requested WD - 1 steps (512 MFMA cycles each) ahead
     v4f wr[WD][CB] = {};                                                   // (WD = 4 measured the same: 196.0 vs 194.6 us on 56x56x64, and costs 32 registers)
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
 #endif
     auto fetch_w = [&](bool advance, int buf) __attribute__((always_inline)) {
         if (abl_w) return;
-        unsigned adv = advance ? CB * 1024 : 0;
+        unsigned adv = advance ? CBT * 1024 : 0;
         asm volatile("" : "+s"(adv));
         wstep += adv;
 #pragma unroll
@@ -218,6 +225,7 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
 #pragma unroll
     for (int q = 1; q < WD - 1; ++q) fetch_w(true, q);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                       // the halo has landed: LDS-DMA is ordered for its own wave by vmcnt alone
+    if constexpr (NW > 1) __syncthreads();                                 // ... and for the sibling wave's pieces by the workgroup's only barrier
     fetch_d(IC<0>{}, IC<0>{}, IC<0>{});
     stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{}); stage(IC<4>{}); stage(IC<5>{}); stage(IC<6>{}); stage(IC<7>{});
     stage(IC<8>{}); stage(IC<9>{}); stage(IC<10>{}); stage(IC<11>{}); stage(IC<12>{}); stage(IC<13>{}); stage(IC<14>{}); stage(IC<15>{});
@@ -230,13 +238,13 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
     __builtin_amdgcn_sched_barrier(0);
     if (abl_st && lane != 0) return;                                       // (lane 0 goes on to the clock stamp; 63 of 64 lanes' stores are gone)
     const int oy0 = 2 * (4 * gy + tr), ox0 = 2 * (4 * gx + tc);
-    const int n0 = tile_n * 16 * CB, Cout = p.Cout;
+    const int n0 = (tile_n * NW + wv) * 16 * CB, Cout = p.Cout;
     const float* __restrict__ res = p.res;
     float* __restrict__ out1 = p.out1;
     float* __restrict__ out2 = p.out2;
     const bool relu = p.act == (int)Act::RELU, prelu = p.act == (int)Act::PRELU;
-    float bm[CB][4];                                                       // CB = 2: this lane's 8 bias values, fetched once (no load between the stores)
-    if constexpr (CB == 2) {
+    float bm[CB][4];                                                       // merged form: this lane's 8 bias values, fetched once (no load between the stores)
+    if constexpr (MERGED) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -247,9 +255,9 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int oy = oy0 + a, ox = ox0 + b;
-            if (CB != 2 || oy >= p.Ho || ox >= p.Wo) continue;
+            if (!MERGED || oy >= p.Ho || ox >= p.Wo) continue;
             const size_t pix = ((size_t)gn * p.Ho + oy) * p.Wo + ox;       // (merged convolutions carry no folded BatchNorm: wino2_ok)
-            if constexpr (CB == 2) {                                       // merged sibling convolutions (the only CB = 2 users): per-channel-range destination and activation
+            if constexpr (MERGED) {                                        // merged sibling convolutions: per-channel-range destination and activation
 #pragma unroll
                 for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -277,11 +285,11 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
                 continue;
             }
         }
-    if constexpr (CB == 4) {
+    if constexpr (!MERGED) {
         // Every load of the epilogue goes out BEFORE the first store: bias per pixel (its border class), slope, residual — 36 float4 per lane
         // in flight together, ONE global-memory latency.  (Per pixel "load, wait, compute, store" was four latencies in a row: with the
         // stores masked to one lane of 64 the epilogue still cost 33 of the layer's 195 us — it was never the traffic.)
-        const int n0 = tile_n * 16 * CB + 4 * kq;
+        const int n0 = (tile_n * NW + wv) * 16 * CB + 4 * kq;
         bool live[4]; size_t row[4]; v4f b4[4][CB], r4[4][CB], sl[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) sl[cb] = prelu ? *reinterpret_cast<const v4f*>(p.slope + n0 + 16 * cb) : v4f{1.f, 1.f, 1.f, 1.f};
@@ -325,24 +333,24 @@ __global__ __launch_bounds__(64, 2) void wino2_kernel(const ConvArgs p, const in
 
 bool shape_ok(int Cin, int Cout) { return Cin == 64 && (Cout % 64 == 0 || Cout <= 32); }   // (<= 32: merged outputs only, see wino2_ok)
 
-template <int CB>
+template <int CB, int NW, bool MERGED>
 void launch_cb(const ConvArgs& a, hipStream_t s) {
     const int tgy = ((a.H + 1) / 2 + 3) / 4, tgx = ((a.W + 1) / 2 + 3) / 4;
     const long n_tg = (long)a.B * tgy * tgx;
-    const int tiles_n = (a.Cout + 16 * CB - 1) / (16 * CB);
+    const int tiles_n = (a.Cout + 16 * CB * NW - 1) / (16 * CB * NW);      // column tiles of 16 CB NW channels: one workgroup each
     // The kernel XORs swizzle keys into ABSOLUTE LDS addresses (rb[] ^ (j << 6)): that equals base + (offset ^ key) only while the dynamic
     // LDS base is 256-byte aligned, i.e. 0 — true as long as the kernel declares no static __shared__ object.  Checked once per instantiation.
     static const bool lds_ok = [] {
         hipFuncAttributes fa{};
-        FH_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&wino2_kernel<CB>)));
+        FH_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&wino2_kernel<CB, NW, MERGED>)));
         return fa.sharedSizeBytes % 256 == 0;
     }();
     if (!lds_ok) throw std::runtime_error("wino2: static LDS moved the halo off its 256-byte alignment (see the address XOR in fetch_d)");
     KernelTimer& timer = KernelTimer::get();
     timer.begin(s);
-    hipLaunchKernelGGL((wino2_kernel<CB>), dim3((unsigned)(n_tg * tiles_n)), dim3(64), 25600, s, a, tiles_n, tgx, tgy, (int)n_tg);
+    hipLaunchKernelGGL((wino2_kernel<CB, NW, MERGED>), dim3((unsigned)(n_tg * tiles_n)), dim3(64 * NW), 25600, s, a, tiles_n, tgx, tgy, (int)n_tg);
     // booked with the FLOPs the matrix cores EXECUTE (padded tiles / channels included); bytes slot: the layer's direct-form FLOPs, as tag 7
-    timer.end(s, 12, 2.0 * 16 * 16.0 * (double)n_tg * a.Cin * (16.0 * CB * tiles_n), a.t_flops);
+    timer.end(s, 12, 2.0 * 16 * 16.0 * (double)n_tg * a.Cin * (16.0 * CB * NW * tiles_n), a.t_flops);
 }
 
 }  // namespace
@@ -412,8 +420,11 @@ void launch_wino2(const ConvArgs& a_in, hipStream_t s) {
     if (ablate >= 0 && !g_w2_clock) { void* q = nullptr; if (hipMalloc(&q, sizeof(float) << 17) == hipSuccess) g_w2_clock = (float*)q; }
     if (g_w2_clock) (void)hipMemsetAsync(g_w2_clock, 0, sizeof(float) << 17, s);
     a.slabs = g_w2_clock;
-    if (a.Cout <= 32) launch_cb<2>(a, s);
-    else launch_cb<4>(a, s);
+    // plain 64-channel column tiles: two waves of 32 channels around one halo (FACEHIP_WINO2_NW=1: the one-wave form of round 4, for A / B timing)
+    static const int nw = [] { const char* e = getenv("FACEHIP_WINO2_NW"); return e ? atoi(e) : 2; }();
+    if (a.Cout <= 32) launch_cb<2, 1, true>(a, s);
+    else if (nw == 2) launch_cb<2, 2, false>(a, s);
+    else launch_cb<4, 1, false>(a, s);
 }
 
 }  // namespace fh

@@ -280,6 +280,14 @@ FH_API int fh_conv_winograd_dev(const float* d_in, const float* w_ohwi_host, con
  * act = 0 none / 1 ReLU / 2 PReLU (d_slope [cout]) ...; d_res = optional residual of the output's shape.  Synchronous. */
 FH_API int fh_conv_wino2_dev(const float* d_in, const float* w_ohwi_host, const float* d_bias, const float* d_slope, const float* d_res,
                              float* d_out, int batch, int h, int w, int cin, int cout, int act, int bias_cls, void* stream);
+/* The full argument set of that kernel: d_out2 = d_out * d_s2 + d_t2 (a following block's BatchNorm; any of d_out / d_out2 may be NULL
+ * when the other is given), and the MERGED form SCRFD's heads use — n_outs (1..3) sibling convolutions evaluated as one with cout <= 32
+ * channels in all: output g takes channels [oc0[g], oc0[g + 1]) into d_outs[g] ([pixels][oc0[g + 1] - oc0[g]]) through activation
+ * oact[g] (0 none / 1 ReLU / 3 sigmoid); no residual, second output or bias classes in that form.  Synchronous. */
+FH_API int fh_conv_wino2_ex_dev(const float* d_in, const float* w_ohwi_host, const float* d_bias, const float* d_slope, const float* d_res,
+                                float* d_out, float* d_out2, const float* d_s2, const float* d_t2, int n_outs, float* const* d_outs,
+                                const int* oc0, const int* oact, int batch, int h, int w, int cin, int cout, int act, int bias_cls,
+                                void* stream);
 /* Diagnostic builds of conv_wino2.hip (-DFACEHIP_W2_PROF, scripts/wino2_prof.sh, FACEHIP_W2_ABLATE set): median shader clock in MHz the
  * waves of the last wino2 launch measured (s_memtime against the 100 MHz s_memrealtime).  0 in production builds. */
 FH_API double fh_debug_wino2_clock_mhz(void);

@@ -5,6 +5,7 @@ Winograd transform of the 28x28 stage; small-batch GEMM tiles.
 Same bars as tests/test_gpu_parity.py: integer / byte / index work bit-exact, fp32 network outputs within the tolerance written
 beside each assert, embeddings within 1e-3 cosine of the oracle (north star).
 """
+import ctypes
 import os
 import subprocess
 import sys
@@ -245,3 +246,78 @@ def test_channel_sliced_fused_transform_on_28x28_maps_matches_oracle_and_unfused
     for i in (0, n // 2, n - 1):
         r = oracle.run_graph(orec.g, {orec.g.inputs[0][0]: oracle.rec_preprocess(crops[i])[None]})[orec.g.outputs[0][0]].reshape(-1)
         np.testing.assert_allclose(outs[0][i], r, rtol=2e-4, atol=2e-4 * np.abs(r).max(), err_msg=f"slot {i}")
+
+
+WINO2_MERGED_CASES = [
+    # B, H,  W,  splits of the <= 32 merged channels, activations per group (0 none / 1 ReLU / 3 sigmoid)
+    (3, 80, 80, (2, 8, 20), (3, 0, 0)),         # SCRFD's merged heads: score (sigmoid) / bbox / kps of one stride, 30 of 32 channels live
+    (2, 20, 20, (3, 8, 19), (3, 0, 1)),         # odd group sizes: channel pairs that straddle two destinations, unaligned 8-byte pairs
+    (5, 40, 40, (1, 4, 10), (3, 0, 0)),         # 15 channels: the second 16-channel block is all padding
+    (2, 13, 9, (32,), (1,)),                    # one destination, ragged map (tile groups hanging over both borders)
+    (1, 20, 20, (5, 27), (0, 3)),               # two destinations
+]
+
+
+@pytest.mark.parametrize("B,H,W,splits,acts", WINO2_MERGED_CASES)
+def test_wino2_merged_sibling_epilogue_matches_oracle(B, H, W, splits, acts):
+    """The CB = 2 form of conv_wino2.hip in isolation (round-4 advisor finding: it only ever ran inside whole-network tests): sibling
+    3x3 convolutions of one 64-channel map evaluated as ONE convolution of <= 32 channels whose channel ranges go to separate
+    destinations through separate activations — SCRFD's score / bbox / kps heads per stride (the Conv + Sigmoid nodes at the end of
+    session_->Run, face_detector.cpp:179-183).  Each destination against the oracle's direct fp32 convolution of its own filter slice,
+    5e-5 absolute as for the plain form; sigmoid outputs 1e-6."""
+    cout = sum(splits)
+    rng = np.random.default_rng(B * 100 + H + cout)
+    x = rng.standard_normal((B, 64, H, W)).astype(np.float32)
+    w = (rng.standard_normal((cout, 64, 3, 3)) / np.sqrt(64 * 9)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    ref = oracle.conv2d(x, w, None, 1, 1, 1) + bias[None, :, None, None]
+    oc0 = np.concatenate([[0], np.cumsum(splits)]).astype(np.int32)
+    outs = [torch.full((B, H, W, c), float("nan"), device="cuda") for c in splits]
+    ptrs = (ctypes.c_void_p * len(splits))(*[o.data_ptr() for o in outs])
+    oact = np.array(acts, np.int32)
+    xd, bd = dev(x.transpose(0, 2, 3, 1)), dev(bias)
+    w_ohwi = np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(cout, 9, 64))
+    rc = fa.lib().fh_conv_wino2_ex_dev(xd.data_ptr(), w_ohwi.ctypes.data, bd.data_ptr(), None, None, None, None, None, None, len(splits),
+                                       ctypes.cast(ptrs, ctypes.c_void_p), oc0.ctypes.data, oact.ctypes.data, B, H, W, 64, cout, 0, 0, None)
+    assert rc == 0, fa._lib.last_error()
+    torch.cuda.synchronize()
+    for g, (c, a) in enumerate(zip(splits, acts)):
+        r = ref[:, oc0[g]:oc0[g + 1]]
+        r = np.maximum(r, 0) if a == 1 else 1.0 / (1.0 + np.exp(-r.astype(np.float64))) if a == 3 else r
+        got = outs[g].cpu().numpy().transpose(0, 3, 1, 2)
+        assert not np.isnan(got).any(), g
+        np.testing.assert_allclose(got, r.astype(np.float32), rtol=0, atol=5e-5 if a != 3 else 2e-5, err_msg=f"destination {g}")
+
+
+def test_wino2_second_output_and_argument_checks():
+    """`out2 = out1 * s2 + t2` of the plain form (a following block's BatchNorm written beside the plain output; IResNet's
+    `+bn2nd` layers) with and without out1, and the argument checks of the test entry point."""
+    B, H, W, C = 2, 24, 24, 64
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    w = (rng.standard_normal((C, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32)
+    bias = rng.standard_normal(C).astype(np.float32); s2 = rng.uniform(0.5, 1.5, C).astype(np.float32); t2 = rng.standard_normal(C).astype(np.float32)
+    res = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    ref = oracle.conv2d(x, w, None, 1, 1, 1) + bias[None, :, None, None] + res.transpose(0, 3, 1, 2)
+    ref2 = ref * s2[None, :, None, None] + t2[None, :, None, None]
+    xd, bd, rd, s2d, t2d = dev(x.transpose(0, 2, 3, 1)), dev(bias), dev(res), dev(s2), dev(t2)
+    w_ohwi = np.ascontiguousarray(w.transpose(0, 2, 3, 1).reshape(C, 9, C))
+    L = fa.lib()
+    for with_out1 in (True, False):
+        o1 = torch.full((B, H, W, C), float("nan"), device="cuda"); o2 = torch.full((B, H, W, C), float("nan"), device="cuda")
+        rc = L.fh_conv_wino2_ex_dev(xd.data_ptr(), w_ohwi.ctypes.data, bd.data_ptr(), None, rd.data_ptr(), o1.data_ptr() if with_out1 else None,
+                                    o2.data_ptr(), s2d.data_ptr(), t2d.data_ptr(), 0, None, None, None, B, H, W, C, C, 0, 0, None)
+        assert rc == 0, fa._lib.last_error()
+        torch.cuda.synchronize()
+        if with_out1:
+            np.testing.assert_allclose(o1.cpu().numpy().transpose(0, 3, 1, 2), ref, rtol=0, atol=5e-5)
+        else:
+            assert torch.isnan(o1).all()          # untouched
+        np.testing.assert_allclose(o2.cpu().numpy().transpose(0, 3, 1, 2), ref2, rtol=0, atol=1e-4)
+    o1 = torch.zeros((B, H, W, C), device="cuda")
+    assert L.fh_conv_wino2_ex_dev(xd.data_ptr(), w_ohwi.ctypes.data, bd.data_ptr(), None, None, o1.data_ptr(), o1.data_ptr(), None, None, 0, None,
+                                  None, None, B, H, W, C, C, 0, 0, None) == -1           # second output without scale / shift
+    assert L.fh_conv_wino2_ex_dev(xd.data_ptr(), w_ohwi.ctypes.data, bd.data_ptr(), None, None, o1.data_ptr(), None, None, None, 0, None,
+                                  None, None, 0, H, W, C, C, 0, 0, None) == -1           # empty batch
+    assert L.fh_conv_wino2_ex_dev(xd.data_ptr(), w_ohwi.ctypes.data, bd.data_ptr(), None, None, o1.data_ptr(), None, None, None, 0, None,
+                                  None, None, B, H, W, C, 48, 0, 0, None) == -1          # plain layers: whole 64-channel column tiles
