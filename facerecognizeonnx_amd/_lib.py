@@ -125,6 +125,7 @@ PROTOTYPES = {
     "fh_det_set_cus": (_i, [_vp, _i]),
     "fh_rec_set_cus": (_i, [_vp, _i]),
     "fh_debug_streamk": (_i, [_i, _i]),
+    "fh_debug_wino_slots": (_i, [_i]),
     "fh_set_graph_replay": (_i, [_i]),
     "fh_det_workspace_dev": (_vp, [_vp]),
     "fh_det_graph_stats": (_i, [_vp, _vp]),

@@ -875,6 +875,7 @@ int fh_rec_graph_stats(fh_rec* r, long long* replays) {
     if (replays) *replays = r->gcall.replays + r->gcall_simple.replays;
     return (int)(r->gcall.nodes ? r->gcall.nodes : r->gcall_simple.nodes);
 }
+int fh_debug_wino_slots(int slots) { fh::wino_debug_slots(slots); return 0; }
 int fh_debug_streamk(int drop_publish, int timeout_ms) { fh::conv_debug_streamk(drop_publish, timeout_ms); return 0; }
 int fh_conv_forward_dev(const float* in, const float* wt, const float* bias, float* out, int batch, int h, int w, int cin, int cout,
                         int ks, int stride, int kpad, int cfg, void* stream) {

@@ -193,6 +193,7 @@ bool wino_mix_layout(int B, int H, int W, int Cin, int Cout, WinoPlanes* out);
 void launch_wino_mix(const ConvArgs& a, const WinoPlanes& pl, const float* M, float* Vnext, int feed_aff, const float* in_scale,
                      const float* in_shift, bool pack_next, hipStream_t s);
 void wino_filter_transform(const double g[9], double u[36]);
+void wino_debug_slots(int slots);            // test hook: workgroup slots the multi-tile Winograd GEMM sizes its grid for (0 = the device)
 long wino_rows(long tiles);                  // rows per frequency plane of the V / M workspaces (tiles rounded up to 256)     // host: G g G^T of one 3x3 filter
 int conv_wt_rows(int Cout);                   // packed weight rows (Cout rounded up to 128)
 size_t conv_slab_floats();

@@ -589,6 +589,121 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __rest
             *reinterpret_cast<v4f*>(orow + j * 32 + 8 * g) = v4f{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
 }
 
+// ---- the same GEMM with several tiles per workgroup (round 5) ------------------------------------------------------------------------
+// A launch of more tiles than resident workgroups runs in rounds, and in every round each workgroup pays the same two serial pieces around
+// its K loop: the first chunk's trip from L2 / the Infinity Cache (nothing to compute meanwhile) and the store tail (the matrix pipe idles
+// until the workgroup retires).  Here a workgroup walks tiles vb = blockIdx.x, + gridDim.x, ... and, once the K loop of a tile has passed its
+// last barrier, requests the NEXT tile's first chunk into the tile buffer the turn-around scratch does not use, then stores: the DMA flies
+// under the epilogue and the store acknowledgements under the next tile's first chunk.  The wait in front of the next K loop is COUNTED
+// (`s_waitcnt vmcnt(stores issued since the DMA)`: vector-memory operations retire in issue order, so that covers the DMA and leaves the
+// stores in flight) with a raw s_barrier — `__syncthreads()` would drain the stores too.  Results are bit-identical to wino_gemm_kernel
+// (same tile arithmetic in the same order).  MEASURED AND NOT THE DEFAULT (see wino_pers_enabled): kept behind FACEHIP_WINO_PERS=1 as the
+// record of the experiment the round-4 review asked for, with its own oracle test.
+template <int BN, int OCC>
+__global__ __launch_bounds__(256, OCC) void wino_gemm_pers_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ M,
+                                                                 const int K, const int N, const WinoPlanes pl, const long wt_gs,
+                                                                 const int tiles_n, const int chunks, const int ntiles) {
+    constexpr int BM = 128, TN = BN / 32, AL = BM / 32, BL = BN / 32;
+    constexpr int BUF = (BM + BN) * 8;                                      // float4 slots per tile buffer
+    __shared__ v4f lds[2][BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh2 = lane >> 5, fsw = (fr >> 1) & 7;
+    const int lrow = tid >> 3;
+    const int lqs = (tid & 7) ^ ((lrow >> 1) & 7);              // source k-column of this lane (swizzle on the source side)
+    const size_t row32 = (size_t)32 * K;
+    // XCD-contiguous tile order over the VIRTUAL block index (gridDim.x is a multiple of 8: vb % 8 = this workgroup's XCD for every vb)
+    const int q = ntiles >> 3, r8 = ntiles & 7;
+    auto tile_of = [&](int vb) { const int x = vb & 7; return x * q + min(x, r8) + (vb >> 3); };
+    const float* a_src; const float* b_src;
+    auto point_at = [&](int tile) {
+        const int tile_n = tile % tiles_n, tile_m = tile / tiles_n;
+        const float* Ug = U + (size_t)wino_plane_freq(pl, tile_m) * wt_gs;
+        a_src = V + (size_t)(tile_m * BM + lrow) * K + lqs * 4;
+        b_src = Ug + (size_t)(tile_n * BN + lrow) * K + lqs * 4;
+    };
+    auto load_chunk = [&](int buf) {
+        v4f* const dA = &lds[0][wid * 64] + buf * BUF;
+        v4f* const dB = &lds[0][BM * 8 + wid * 64] + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < AL; ++i) wino_dma16(a_src + i * row32, dA + i * 32 * 8);
+#pragma unroll
+        for (int i = 0; i < BL; ++i) wino_dma16(b_src + i * row32, dB + i * 32 * 8);
+        a_src += 32; b_src += 32;
+    };
+    constexpr int JB = 1, W = JB * 32, PITCH = W + 4, RPI = 64 / (W / 4);    // turn-around in 32-column blocks: 4 waves x 32 x 36 floats = 18 KB <= one buffer
+    static_assert(4 * 32 * PITCH * sizeof(float) <= BUF * sizeof(v4f), "store scratch must fit ONE tile buffer");
+    constexpr int NSTORE = TN * (32 / RPI);                                 // global store instructions per wave and tile
+    int base = 0;                                                           // buffer that holds the current tile's chunk 0
+    int vb = blockIdx.x;
+    point_at(tile_of(vb));
+    load_chunk(0);
+    __syncthreads();
+    for (;;) {
+        const int tile = tile_of(vb);
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+        v16f acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int kc = 0; kc < chunks; ++kc) {
+            const int buf = (base + kc) & 1;
+            if (kc + 1 < chunks) load_chunk(buf ^ 1);
+            const v4f* X = lds[buf] + (wid * 32 + fr) * 8;
+            const v4f* Wt = lds[buf] + BM * 8 + fr * 8;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int col = (2 * s4 + fh2) ^ fsw;
+                const v4f xv = X[col];
+                v4f w[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) w[j] = Wt[j * 32 * 8 + col];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[j][e], xv[e], acc[j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+        // every wave is past the last chunk: both buffers are free.  last = the buffer of the final chunk -> scratch; the other -> next tile
+        const int last = (base + chunks - 1) & 1;
+        const int nvb = vb + gridDim.x;
+        const bool more = nvb < ntiles;
+        if (more) {
+            point_at(tile_of(nvb));
+            load_chunk(last ^ 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);                              // (the DMA is issued in front of the stores it is counted against)
+#endif
+        }
+        {
+            float* const blk = reinterpret_cast<float*>(&lds[last][0]) + wid * 32 * PITCH;
+            const int rr = lane / (W / 4), cq = lane % (W / 4);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                wave_lds_order();
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<v4f*>(blk + fr * PITCH + 8 * g + 4 * fh2) = v4f{acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                wave_lds_order();
+                float* const obase = M + (size_t)(m0 + wid * 32 + rr) * N + n0 + j * W + 4 * cq;
+#pragma unroll
+                for (int i = 0; i < 32 / RPI; ++i)
+                    *reinterpret_cast<v4f*>(obase + (size_t)i * RPI * N) = *reinterpret_cast<const v4f*>(blk + (rr + i * RPI) * PITCH + 4 * cq);
+            }
+        }
+        if (!more) break;
+        vb = nvb; base = last ^ 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the next tile's chunk 0 has landed once all but the NSTORE youngest vector-memory operations (this tile's stores) are done
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSTORE) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+
 // Split-bf16 form of the same GEMM (opt-in precision mode): V and U hold (hi, mid) bf16 pairs in 32-bit words, everything up to the
 // fragment reads is byte-for-byte the f32 kernel.  A lane takes 8 consecutive k of its row per 16-deep MFMA step (two ds_read_b128),
 // separates the hi and the mid halves with v_perm_b32 and issues v_mfma_f32_32x32x16_bf16 three times: mid*hi + hi*mid + hi*hi
@@ -703,6 +818,19 @@ void launch_wino_input(const ConvArgs& a, float* V, const float* in_scale, const
 // bf16x2: V and wt36 hold split-bf16 words (wino_gemm_ok_bf16x2 says whether this layer's GEMM has that form)
 bool wino_gemm_ok_bf16x2(int Cin, int Cout) { return Cout % 64 == 0 && Cin % 32 == 0; }
 
+static int g_wino_slots_override = 0;                           // test hook (fh_debug_wino_slots): pretend the chip has this many workgroup slots per launch
+void wino_debug_slots(int slots) { g_wino_slots_override = slots > 0 ? (slots + 7) / 8 * 8 : 0; }
+static long wino_slots(int occ, int cus) { return g_wino_slots_override ? g_wino_slots_override : (long)occ * (cus > 0 ? cus : 256) / 8 * 8; }
+
+static int wino_pers_enabled() {
+    static int v = -1;
+    // default OFF: measured 0.4-2 % SLOWER than one tile per workgroup on every Winograd layer of IResNet-50 at B = 128 and 256 (GEMM sum
+    // 3 054 against 3 043 us, 5 745 against 5 703: profiles/r05_notes.md) — the hardware's dynamic refill of freed slots is worth more than
+    // the hidden first-chunk latency.  1 = on (A / B timing); the test hook fh_debug_wino_slots switches it on for the walk tests.
+    if (v < 0) { const char* e = getenv("FACEHIP_WINO_PERS"); v = e ? atoi(e) : 0; }
+    return v || g_wino_slots_override;
+}
+
 static int wino_mix_enabled() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("FACEHIP_WINO_MIX"); v = e ? atoi(e) : 1; }          // (0 = uniform F(4x4) tiling everywhere: A / B timing)
@@ -725,8 +853,8 @@ static bool wino_bn128(bool mixed) {
 static bool wino_pick_bn128(long row_tiles, int Cout, bool mixed, int cus) {
     static const int force = [] { const char* e = getenv("FACEHIP_WINO_BN128"); return e ? atoi(e) : -1; }();
     if (force >= 0) return wino_bn128(mixed);
-    const long cu = cus > 0 ? cus : 256;
-    const long wide = (row_tiles * (Cout / 128) + 2 * cu - 1) / (2 * cu) * 4, narrow = (row_tiles * (Cout / 64) + 3 * cu - 1) / (3 * cu) * 3;
+    const long sw = wino_slots(2, cus), sn = wino_slots(3, cus);
+    const long wide = (row_tiles * (Cout / 128) + sw - 1) / sw * 4, narrow = (row_tiles * (Cout / 64) + sn - 1) / sn * 3;
     if (wide != narrow) return wide < narrow;
     return wino_bn128(mixed);
 }
@@ -791,10 +919,19 @@ void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, floa
             if (!wino_gemm_ok_bf16x2(a.Cin, a.Cout)) throw std::runtime_error("winograd: this layer has no split-bf16 GEMM");
             hipLaunchKernelGGL((wino_gemm_bf16x2_kernel<64, 3>), dim3((unsigned)((rows / 128) * (a.Cout / 64))), dim3(256), 0, s, V, wt36, M, a.Cin,
                                a.Cout, pl, g.wt_gs, a.Cout / 64, chunks);
-        } else if (wide && a.Cout % 128 == 0 && wino_pick_bn128(rows / 128, a.Cout, mix != nullptr, a.cus))
-            hipLaunchKernelGGL((wino_gemm_kernel<128, 2>), dim3((unsigned)((rows / 128) * (a.Cout / 128))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
-                               pl, g.wt_gs, a.Cout / 128, chunks);
-        else if (wide) {
+        } else if (wide && a.Cout % 128 == 0 && wino_pick_bn128(rows / 128, a.Cout, mix != nullptr, a.cus)) {
+            const long nt = (rows / 128) * (a.Cout / 128), slots = wino_slots(2, a.cus);
+            if (wino_pers_enabled() && nt > slots)
+                hipLaunchKernelGGL((wino_gemm_pers_kernel<128, 2>), dim3((unsigned)slots), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout, pl, g.wt_gs,
+                                   a.Cout / 128, chunks, (int)nt);
+            else
+                hipLaunchKernelGGL((wino_gemm_kernel<128, 2>), dim3((unsigned)nt), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout, pl, g.wt_gs, a.Cout / 128,
+                                   chunks);
+        } else if (wide && wino_pers_enabled() && (rows / 128) * (a.Cout / 64) > wino_slots(3, a.cus)) {
+            const long nt = (rows / 128) * (a.Cout / 64), slots = wino_slots(3, a.cus);
+            hipLaunchKernelGGL((wino_gemm_pers_kernel<64, 3>), dim3((unsigned)slots), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout, pl, g.wt_gs, a.Cout / 64,
+                               chunks, (int)nt);
+        } else if (wide) {
 #ifdef FACEHIP_WINO_ABL
             static const int abl = [] { const char* e = getenv("FACEHIP_WINO_ABL"); return e ? atoi(e) : 0; }();
             const dim3 grid((unsigned)((rows / 128) * (a.Cout / 64)));

@@ -305,6 +305,10 @@ FH_API int fh_rec_graph_stats(fh_rec* r, long long* replays);
  * next call on the same handle (or fh_det_sync / fh_rec_sync) returns FH_ERR_DEVICE ("stream-K hand-off timed out ...") instead of
  * the process hanging with the GPU; other handles are unaffected. */
 FH_API int fh_debug_streamk(int drop_publish, int timeout_ms);
+/* Test hook of the multi-tile Winograd GEMM (winograd.hip wino_gemm_pers_kernel): launches with more tiles than resident workgroup
+ * slots walk several tiles per workgroup; slots > 0 makes the launcher pretend the device has that many (rounded up to 8), so that small
+ * test layers take the multi-tile path with many tiles per workgroup; 0 restores the device's own count. */
+FH_API int fh_debug_wino_slots(int slots);
 FH_API int fh_conv_wt_rows(int cout);
 /* host: weights [cout][ksize*ksize][cin] (O,H,W,I) -> the kernel's packed image [fh_conv_wt_rows][fh_conv_kpad] */
 FH_API int fh_conv_pack_weights(const float* w_ohwi, int cout, int cin, int ksize, float* dst_packed);

@@ -321,3 +321,37 @@ def test_wino2_second_output_and_argument_checks():
                                   None, None, 0, H, W, C, C, 0, 0, None) == -1           # empty batch
     assert L.fh_conv_wino2_ex_dev(xd.data_ptr(), w_ohwi.ctypes.data, bd.data_ptr(), None, None, o1.data_ptr(), None, None, None, 0, None,
                                   None, None, B, H, W, C, 48, 0, 0, None) == -1          # plain layers: whole 64-channel column tiles
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,slots", [
+    (2, 14, 14, 256, 256, 8),          # 128x128 tiles (Cout % 128 == 0 picks them when tiles spill past the slots): 9 tiles per workgroup
+    (1, 28, 28, 128, 128, 8),          # 128x64 tiles, K = 128: four chunks per tile, an even number (the tile buffers swap roles per tile)
+    (3, 7, 7, 512, 128, 16),           # K = 512
+    (2, 13, 10, 160, 64, 8),           # K = 160: FIVE chunks, an odd number — the next tile's first chunk lands in the other buffer
+    (64, 14, 14, 128, 64, 8),          # mixed F(4x4) / F(2x2) layout: plane classes change inside a workgroup's walk
+    (2, 14, 14, 256, 256, 24),         # three tiles per workgroup, the last walk ragged
+])
+def test_multi_tile_winograd_gemm_walks_match_oracle_and_single_tile_form(B, H, W, Cin, Cout, slots):
+    """`wino_gemm_pers_kernel` (several GEMM tiles per workgroup, the next tile's first chunk requested in front of the store tail,
+    counted `vmcnt` wait): with the slot count forced down (fh_debug_wino_slots) every workgroup walks many tiles.  The layer must match
+    the oracle's direct convolution at the Winograd bar (2e-4 abs: the Conv nodes inside session_->Run, face_recognizer.cpp:279-283)
+    and equal the one-tile-per-workgroup launch BIT FOR BIT (same tile arithmetic in the same order)."""
+    rng = np.random.default_rng(B * 1000 + H * 10 + Cin + slots)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    ref = oracle.conv2d(x, w, b, 1, 1, 1)
+    ohwi = np.ascontiguousarray(w.transpose(0, 2, 3, 1))
+    xd, bd = dev(x.transpose(0, 2, 3, 1)), dev(b)
+    L = fa.lib()
+    outs = []
+    try:
+        for s in (slots, 1 << 20):                                         # walk / one tile per workgroup (more slots than tiles)
+            assert L.fh_debug_wino_slots(s) == 0
+            out = torch.full((B, H, W, Cout), float("nan"), device="cuda")
+            assert L.fh_conv_winograd_dev(xd.data_ptr(), ohwi.ctypes.data, bd.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, 0) == 0, fa._lib.last_error()
+            outs.append(out.cpu().numpy())
+    finally:
+        L.fh_debug_wino_slots(0)
+    assert np.array_equal(outs[0], outs[1])
+    np.testing.assert_allclose(outs[0].transpose(0, 3, 1, 2), ref, rtol=0, atol=2e-4)
