@@ -27,7 +27,7 @@
 //
 // A 32-column form of the same algorithm (v_mfma_f32_32x32x2_f32: 4 x 7 | 8 tiles per wave, two tile groups x two 32-channel halves per
 // 4-wave workgroup, 32-channel halo chunks, weights through an LDS stage or registers, persistent or not) was built first and measured
-// equal: 185-197 us on 56x56x64 -> 64 at B = 128 for every variant, against 285 us direct (DESIGN.md 3.1l has the ablation that says why:
+// equal: 185-197 us on 56x56x64 -> 64 at B = 128 for every variant, against 285 us direct (docs/kernels.md 3.1l has the ablation that says why:
 // the costs ADD — the kernel behaves like one bound by energy, not by any one pipe).  This form is kept: exact fit on 56 / 112 / 80 / 40-wide
 // maps, V formed once per tile instead of once per channel half, no barrier, and the merged-output epilogue.
 //
@@ -79,7 +79,7 @@ template <int V> struct IC { static constexpr int value = V; };          // comp
 // NW = waves per workgroup that share ONE halo: wave w computes the 16 CB channels [16 CB w, 16 CB (w + 1)) of the workgroup's 16 CB NW-channel
 // column tile (NW = 1: the original one-wave form).  MERGED selects the merged-sibling epilogue (per-channel-range destinations).
 // NW = 2, CB = 2 on the plain 64-channel layers: the 25.6 KB halo limits a CU to six workgroups either way, so six waves of 226 registers
-// (1.5 per SIMD: two SIMDs carry two waves, two carry one) become twelve of 112 (three per SIMD) — see DESIGN.md.
+// (1.5 per SIMD: two SIMDs carry two waves, two carry one) become twelve of 112 (three per SIMD) — DESIGN.md 3.1.
 template <int CB, int NW, bool MERGED>
 __global__ __launch_bounds__(64 * NW, NW == 1 ? 2 : 3) void wino2_kernel(const ConvArgs p, const int tiles_n, const int tgx, const int tgy, const int n_tg) {
     extern __shared__ v4f w2sm[];

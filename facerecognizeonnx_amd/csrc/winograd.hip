@@ -495,6 +495,9 @@ __device__ __forceinline__ void wino_store_lines(const v16f (&acc)[TN], float* s
     }
 }
 
+// Round 5 measured two more arrangements of this loop, both bit-identical and both SLOWER, neither kept in the tree: the next chunk's 8 (6)
+// LDS-DMA requests spread over the four k-steps between the MFMAs with the next step's fragments read a half-step ahead (GEMM sum of
+// IResNet-50 at B = 128: 3 189-3 227 us against 3 127-3 160 in the same runs), and several tiles per workgroup (wino_gemm_pers_kernel below).
 // ABL (diagnostic instantiations only, results are garbage): 1 = no loads in the K loop (the first chunk is computed over and over),
 // 2 = no LDS reads (operands stay in registers), 4 = no barriers in the K loop, 8 = no stores, 16 = stores straight from registers
 template <int BN, int OCC, int ABL = 0>
@@ -941,7 +944,7 @@ void launch_wino_gemm(const ConvArgs& a, const float* wt36, const float* V, floa
 #undef WABL
 #else
             hipLaunchKernelGGL((wino_gemm_kernel<64, 3>), dim3((unsigned)((rows / 128) * (a.Cout / 64))), dim3(256), 0, s, V, wt36, M, a.Cin, a.Cout,
-                               pl, g.wt_gs, a.Cout / 64, chunks);
+                                   pl, g.wt_gs, a.Cout / 64, chunks);
 #endif
         }
         else
