@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--of-world", type=int, default=8)
     ap.add_argument("--stream-priority", default="rec", choices=["rec", "det", "none"],
                     help="streaming e2e form: which of the two HIP streams gets the higher priority (tuning)")
+    ap.add_argument("--sustain-steps", type=int, default=200, help="extra steps of the same form right after the timed region, reported as "
+                    "`sustained` beside `value` (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=32)
@@ -601,6 +603,22 @@ def main():
     # Kernel-level roofline leg: the same steps again with the library's per-launch HIP events switched on.
     # It runs right AFTER the timed region (not inside it) because the ~250 event records per step cost
     # ~6 % of the step (22.8 vs 21.5 ms); `value` must not carry the instrumentation.
+    # Sustained leg: the timed region above is a fraction of a second (K = 20 steps of ~10 ms), which says little about clocks that settle
+    # over seconds (MI355X_MICROARCH.md, DVFS give-back) and is invisible to a 5 s utilisation sampler.  The SAME step, same form, is
+    # therefore repeated for --sustain-steps more steps right after it and reported beside `value` (never as `value`).
+    sustained = None
+    if args.sustain_steps > 0 and args.workload in ("e2e", "embed", "detect") and not args.from_host:
+        torch.cuda.synchronize()
+        tq0 = time.perf_counter()
+        su = 0
+        for _ in range(args.sustain_steps):
+            su += step()
+        torch.cuda.synchronize()
+        sdt = time.perf_counter() - tq0
+        sustained = {"steps": args.sustain_steps, "ms_per_step": 1e3 * sdt / args.sustain_steps, "value": su / sdt,
+                     "unit": "frames/s" if args.workload == "detect" else "faces/s",
+                     "what": "the same step in the same form, repeated right after the timed region on rank 0 (clock settling, visibility to "
+                             "utilisation samplers); `value` stays the K timed steps"}
     serial_dt = None
     if locals().get("pipelined"):                                         # the same K steps once more, one batch at a time on one stream
         step = step_serial
@@ -651,6 +669,7 @@ def main():
             "timed_step_ms_max": step_ms[-1] if step_ms else None,
             "timed_step_ms_source": "HIP events around each of the timed steps on the launch stream, rank 0 (value / ms_per_step stay the "
                                     "barrier-bracketed wall clock, max over ranks)",
+            "sustained": sustained,
             "serial_reference": None if serial_dt is None else {
                 "ms_per_step": 1e3 * serial_dt / max(args.steps, 1), "value": per_step_faces * args.steps / serial_dt, "unit": "faces/s",
                 "what": "the same steps run one batch at a time on one stream (fh_pipeline_run_dev) right after the timed region, rank 0: "
