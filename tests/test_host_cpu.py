@@ -198,6 +198,21 @@ def test_comm_boundary_loads_rccl_and_rejects_bad_arguments_without_a_gpu():
     assert L.fh_timing_num_tags() == 13
 
 
+def test_round5_test_entry_points_validate_their_arguments_without_a_gpu():
+    """Argument errors of the kernel test entry points added in round 5 come back as FH_ERR_ARG before anything touches a device."""
+    L = fa.lib()
+    one = ctypes.c_void_p(16)                                  # a non-null token: every call below must fail on its sizes first
+    assert L.fh_conv_wino2_ex_dev(None, None, None, None, None, None, None, None, None, 0, None, None, None, 1, 8, 8, 64, 64, 0, 0, None) == -1
+    assert L.fh_conv_wino2_ex_dev(one, one, None, None, None, one, None, None, None, 0, None, None, None, 0, 8, 8, 64, 64, 0, 0, None) == -1   # empty batch
+    assert L.fh_conv_wino2_ex_dev(one, one, None, None, None, one, None, None, None, 0, None, None, None, 1, 8, 8, 32, 64, 0, 0, None) == -1   # cin != 64
+    assert L.fh_conv_wino2_ex_dev(one, one, None, None, None, one, None, None, None, 0, None, None, None, 1, 8, 8, 64, 48, 0, 0, None) == -1   # cout % 64
+    assert L.fh_conv_wino2_ex_dev(one, one, None, None, None, one, one, None, None, 0, None, None, None, 1, 8, 8, 64, 64, 0, 0, None) == -1    # out2 without s2 / t2
+    assert L.fh_conv_wino2_ex_dev(one, one, None, None, None, None, None, None, None, 4, one, one, one, 1, 8, 8, 64, 30, 0, 0, None) == -1     # more than 3 merged outputs
+    assert L.fh_conv_wino2_ex_dev(one, one, None, None, None, None, None, None, None, 2, None, one, one, 1, 8, 8, 64, 30, 0, 0, None) == -1    # merged outputs without pointers
+    assert "fh_conv_wino2_dev" in _lib.last_error()
+    assert L.fh_debug_wino_slots(24) == 0 and L.fh_debug_wino_slots(0) == 0
+
+
 def _affine_graph(path, H=24, W=20, C=12, Cout=8):
     """conv -> Mul(scalar) -> Add(per-channel) -> Relu -> Dropout -> conv -> Identity -> Sub(scalar) -> Div(per-channel): the
     element-wise constant ops and pass-through nodes exporters leave in graphs (SCRFD's Scale layers, normalisation nodes)."""
