@@ -39,8 +39,9 @@ def csrc_fingerprint() -> str:
     profile (profiles/traffic.json) to the code it was measured on (bench.py reports `roofline.traffic` only when it still matches)."""
     import hashlib
     h = hashlib.sha256()
+    host_only = {"image_io.cpp", "onnx_reader.cpp", "onnx_reader.h", "comm.cpp"}     # file parsers / RCCL glue: no kernel, no launch decision
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".cpp", ".h")):
+        if f.endswith((".hip", ".cpp", ".h")) and f not in host_only:
             h.update(f.encode()); h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]
 

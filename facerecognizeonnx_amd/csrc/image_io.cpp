@@ -202,6 +202,7 @@ struct Jpeg {
 
     void decode_block_baseline(BitReader& br, int16_t* blk, const Huff& hd, const Huff& ha, int& pred) {
         const int t = decode_symbol(br, hd);
+        if (t > 15) fail("JPEG: bad DC category");              // (a damaged DHT can hold any byte as a symbol; 8-bit files use 0..11)
         const int diff = t ? extend(br.get(t), t) : 0;
         pred += diff;
         blk[0] = (int16_t)pred;
@@ -221,6 +222,7 @@ struct Jpeg {
     }
     void decode_dc_first(BitReader& br, int16_t* blk, const Huff& hd, int& pred, int al) {
         const int t = decode_symbol(br, hd);
+        if (t > 15) fail("JPEG: bad DC category");
         const int diff = t ? extend(br.get(t), t) : 0;
         pred += diff;
         blk[0] = (int16_t)(pred * (1 << al));

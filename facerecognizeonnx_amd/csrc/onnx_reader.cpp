@@ -75,7 +75,7 @@ void read_floats(const Field& f, std::vector<float>& out) {
     size_t n = (size_t)(f.sub.e - f.sub.p) / 4;
     size_t base = out.size();
     out.resize(base + n);
-    memcpy(out.data() + base, f.sub.p, n * 4);
+    if (n) memcpy(out.data() + base, f.sub.p, n * 4);
 }
 
 OnnxTensor read_tensor(Span s) {
@@ -94,7 +94,7 @@ OnnxTensor read_tensor(Span s) {
             case 9: raw = f.sub; break;
             case 10:
                 if (f.wt == 1) { double d; memcpy(&d, &f.v, 8); dd.push_back(d); }
-                else { size_t n = (size_t)(f.sub.e - f.sub.p) / 8; size_t b = dd.size(); dd.resize(b + n); memcpy(dd.data() + b, f.sub.p, n * 8); }
+                else { size_t n = (size_t)(f.sub.e - f.sub.p) / 8; size_t b = dd.size(); dd.resize(b + n); if (n) memcpy(dd.data() + b, f.sub.p, n * 8); }
                 break;
             case 13: case 14:
                 if (f.no == 14 && f.v == 1) throw std::runtime_error("onnx: external tensor data not supported");
@@ -105,8 +105,8 @@ OnnxTensor read_tensor(Span s) {
     size_t nbytes = raw.p ? (size_t)(raw.e - raw.p) : 0;
     if (raw.p) {
         switch (t.dtype) {
-            case 1: t.f.resize(nbytes / 4); memcpy(t.f.data(), raw.p, nbytes / 4 * 4); break;
-            case 7: t.i.resize(nbytes / 8); memcpy(t.i.data(), raw.p, nbytes / 8 * 8); break;
+            case 1: t.f.resize(nbytes / 4); if (nbytes >= 4) memcpy(t.f.data(), raw.p, nbytes / 4 * 4); break;      // (an empty payload: data() may be null)
+            case 7: t.i.resize(nbytes / 8); if (nbytes >= 8) memcpy(t.i.data(), raw.p, nbytes / 8 * 8); break;
             case 6: { t.i.resize(nbytes / 4); for (size_t k = 0; k < nbytes / 4; ++k) { int32_t v; memcpy(&v, raw.p + 4 * k, 4); t.i[k] = v; } break; }
             case 11: { t.f.resize(nbytes / 8); for (size_t k = 0; k < nbytes / 8; ++k) { double v; memcpy(&v, raw.p + 8 * k, 8); t.f[k] = (float)v; } break; }
             default: throw std::runtime_error("onnx: unsupported tensor data_type " + std::to_string(t.dtype));
