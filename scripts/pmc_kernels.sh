@@ -11,7 +11,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY S
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT GRBM_GUI_ACTIVE SQ_WAVES" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmck_${TAG}_$i -- python3 $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $R/gpurun_out/pmck_${TAG}_$i.err
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $R/gpurun_out/pmck_${TAG}_$i -- python3 $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --sustain-steps 0 --no-kernel-timing > /dev/null 2> $R/gpurun_out/pmck_${TAG}_$i.err
   echo "pass $i done"
 done
 python3 - <<PY

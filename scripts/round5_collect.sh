@@ -16,4 +16,4 @@ rm -rf gpurun_out/pmck_r05rec_* gpurun_out/pmck_r05det_*
 bash scripts/pmc_kernels.sh r05rec --serial > gpurun_out/r05_pmc_rec.log 2>&1; echo "pmc e2e done"
 bash scripts/pmc_kernels.sh r05det --workload detect > gpurun_out/r05_pmc_det.log 2>&1; echo "pmc det done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r05_overlap -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-kernel-timing > $R/gpurun_out/r05_overlap_bench.json 2> $R/gpurun_out/r05_overlap.err; echo "overlap trace done"
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/r05_overlap -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --sustain-steps 0 --no-kernel-timing > $R/gpurun_out/r05_overlap_bench.json 2> $R/gpurun_out/r05_overlap.err; echo "overlap trace done"
