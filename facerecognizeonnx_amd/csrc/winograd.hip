@@ -823,7 +823,11 @@ bool wino_gemm_ok_bf16x2(int Cin, int Cout) { return Cout % 64 == 0 && Cin % 32 
 
 static int g_wino_slots_override = 0;                           // test hook (fh_debug_wino_slots): pretend the chip has this many workgroup slots per launch
 void wino_debug_slots(int slots) { g_wino_slots_override = slots > 0 ? (slots + 7) / 8 * 8 : 0; }
-static long wino_slots(int occ, int cus) { return g_wino_slots_override ? g_wino_slots_override : (long)occ * (cus > 0 ? cus : 256) / 8 * 8; }
+static long wino_slots(int occ, int cus) {                   // (a multiple of 8 and never 0: a CU-masked stream may report a handful of CUs)
+    if (g_wino_slots_override) return g_wino_slots_override;
+    const long s = (long)occ * (cus > 0 ? cus : 256) / 8 * 8;
+    return s < 8 ? 8 : s;
+}
 
 static int wino_pers_enabled() {
     static int v = -1;
