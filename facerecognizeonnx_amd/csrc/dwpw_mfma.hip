@@ -715,6 +715,13 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
     // halo of an 8 x 16 output tile under a depthwise stride DS: rows 2 oy - 1 .. 2 oy + 1 -> (8 - 1) DS + 3 rows, same for the columns
     constexpr int HH = (DP_TH - 1) * DS + 3, HWD = (DP_TW - 1) * DS + 3, HALO = HH * HWD;   // 10 x 18 = 180 (DS = 1), 17 x 33 = 561 (DS = 2)
     constexpr int NPF = (HALO * CQ + 255) / 256;                           // prefetched float4 per thread
+    // LDS slot of halo pixel hp = hy * HWD + hx.  Stride 1: hp itself.  Stride 2 (round 5): a row's EVEN columns first, then its odd ones —
+    // lane = output pixel reads input column 2 px + kx, i.e. slot px + (kx >> 1) of plane kx & 1: neighbouring lanes are ONE pixel pitch
+    // (odd in float4) apart.  With interleaved columns they were two apart: every halo index of an instruction had the same parity, 8 bank
+    // quads for the 16 lanes of a ds_read_b128 group, a 2-way conflict on every tap (SQ_LDS_BANK_CONFLICT 0.34 of the LDS cycles, round 4).
+    constexpr int HW2 = (HWD + 1) / 2;
+    auto slot = [](int hp) { if (DS == 1) return hp; const int hy = hp / HWD, hx = hp - hy * HWD; return hy * HWD + (hx & 1) * HW2 + (hx >> 1); };
+    auto tapoff = [](int ky, int kx) { return DS == 1 ? ky * HWD + kx : ky * HWD + (kx & 1) * HW2 + (kx >> 1); };
     extern __shared__ v4f smem[];
     v4f* const halo = smem;                                                // [HALO][PQ]
     v4f* const dwl = halo + HALO * PQ;                                  // [10][CQ]: 9 taps + bias
@@ -744,8 +751,9 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
     //  {4-11, 16-19, 28-31} together; with an odd pixel pitch the 16 addresses fall into 16 different bank quads iff the pixels' linear halo
     //  indices differ mod 16, and a halo row is 18 = 16 + 2 pixels: unrotated, lanes 12 / 13 collide with lanes 26 / 27 and lanes 4 / 5 with
     //  lanes 18 / 19 — every fragment read took 8 LDS cycles instead of 4 (SQ_LDS_BANK_CONFLICT = 27-34 % of SQ_LDS_IDX_ACTIVE, round-4 counters))
-    const int pix = wid * 32 + r, py = pix / DP_TW, px = DS == 1 && (py & 1) ? (pix - py * DP_TW - 2) & (DP_TW - 1) : pix - py * DP_TW;
-    const v4f* const hbase = halo + (py * DS * HWD + px * DS) * PQ + h;    // + (ky * HWD + kx) * PQ + 2 j
+    //  (stride 2 with its column planes: consecutive slots again and a row pitch of 2 * 33 = 66 = 64 + 2 slots — the same rotation)
+    const int pix = wid * 32 + r, py = pix / DP_TW, px = (py & 1) ? (pix - py * DP_TW - 2) & (DP_TW - 1) : pix - py * DP_TW;
+    const v4f* const hbase = halo + (py * DS * HWD + px) * PQ + h;            // + tapoff(ky, kx) * PQ + 2 j   (stride 2: px indexes a column plane)
     const v4f* const dbase = dwl + h;                                      // + tap * CQ + 2 j
     int wrow[TN];
 #pragma unroll
@@ -813,7 +821,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int i = tid + 256 * k;
-            if (i < HALO * CQ) halo[i + i / CQ] = pf[k];              // pixel pitch PQ = CQ + 1
+            if (i < HALO * CQ) { const int hp = i / CQ; halo[slot(hp) * PQ + (i - hp * CQ)] = pf[k]; }   // pixel pitch PQ = CQ + 1
         }
         DWPW_STAMP(1)
         if (t + wgs < run1) prefetch(t + wgs);
@@ -843,7 +851,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg_kernel(const ConvArgs p, co
             const int jj = G / NT, tt = G % NT;
             if (jj >= STEPS) return;
             dv[G % RING] = dbase[(tt == 0 ? 9 : tt - 1) * CQ + 2 * jj];
-            if (tt > 0) hv[G % RING] = hbase[(((tt - 1) / 3) * HWD + (tt - 1) % 3) * PQ + 2 * jj];
+            if (tt > 0) hv[G % RING] = hbase[tapoff((tt - 1) / 3, (tt - 1) % 3) * PQ + 2 * jj];
         };
         v4f an;
         auto consume = [&](int G) __attribute__((always_inline)) {
@@ -919,6 +927,9 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg2_kernel(const ConvArgs p, c
     constexpr int PQ = CQA + 1;                                            // halo pixel pitch in float4 (odd)
     constexpr int HH = (DP_TH - 1) * DS + 3, HWD = (DP_TW - 1) * DS + 3, HALO = HH * HWD;   // 17 x 33 = 561
     constexpr int NPA = (HALO * CQA + 255) / 256, NPB = (HALO * CQB + 255) / 256;
+    constexpr int HW2 = (HWD + 1) / 2;                                     // column planes of the stride-2 halo: see dwpw_reg_kernel
+    auto slot = [](int hp) { const int hy = hp / HWD, hx = hp - hy * HWD; return hy * HWD + (hx & 1) * HW2 + (hx >> 1); };
+    auto tapoff = [](int ky, int kx) { return ky * HWD + (kx & 1) * HW2 + (kx >> 1); };
     extern __shared__ v4f smem[];
     v4f* const halo = smem;                                                // [HALO][PQ]
     v4f* const dwl = halo + HALO * PQ;                                     // [10][CQ]: 9 taps + bias
@@ -941,8 +952,8 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg2_kernel(const ConvArgs p, c
     }
     for (int i = tid; i < 32 * TN; i += 256) pwb[i] = i < Cout ? p.bias[i] : 0.f;
 
-    const int pix = wid * 32 + r, py = pix / DP_TW, px = pix - py * DP_TW;
-    const v4f* const hbase = halo + (py * DS * HWD + px * DS) * PQ + h;    // + (ky * HWD + kx) * PQ + 2 (j - first step of the part)
+    const int pix = wid * 32 + r, py = pix / DP_TW, px = (py & 1) ? (pix - py * DP_TW - 2) & (DP_TW - 1) : pix - py * DP_TW;   // (rotation: see dwpw_reg_kernel)
+    const v4f* const hbase = halo + (py * DS * HWD + px) * PQ + h;         // + tapoff(ky, kx) * PQ + 2 (j - first step of the part)
     const v4f* const dbase = dwl + h;
     int wrow[TN];
 #pragma unroll
@@ -1017,7 +1028,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg2_kernel(const ConvArgs p, c
                 const int jl = G / NT, tt = G % NT;
                 if (jl >= NJ) return;
                 dv[G % RING] = dbase[(tt == 0 ? 9 : tt - 1) * CQ + 2 * (J0 + jl)];
-                if (tt > 0) hv[G % RING] = hbase[(((tt - 1) / 3) * HWD + (tt - 1) % 3) * PQ + 2 * jl];
+                if (tt > 0) hv[G % RING] = hbase[tapoff((tt - 1) / 3, (tt - 1) % 3) * PQ + 2 * jl];
             };
             v4f an;
             auto consume = [&](int G) __attribute__((always_inline)) {
@@ -1053,7 +1064,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg2_kernel(const ConvArgs p, c
 #pragma unroll
         for (int k = 0; k < NPA; ++k) {
             const int i = tid + 256 * k;
-            if (i < HALO * CQA) halo[(i / CQA) * PQ + i % CQA] = pfa[k];
+            if (i < HALO * CQA) halo[slot(i / CQA) * PQ + i % CQA] = pfa[k];
         }
         if (t + wgs < run1) DWPW2_PREFETCH(pfa, voa, NPA, CQA, t + wgs)
         front_barrier();
@@ -1063,7 +1074,7 @@ __global__ __launch_bounds__(256, OCC) void dwpw_reg2_kernel(const ConvArgs p, c
 #pragma unroll
         for (int k = 0; k < NPB; ++k) {
             const int i = tid + 256 * k;
-            if (i < HALO * CQB) halo[(i / CQB) * PQ + i % CQB] = pfb[k];
+            if (i < HALO * CQB) halo[slot(i / CQB) * PQ + i % CQB] = pfb[k];
         }
         if (t + wgs < run1) DWPW2_PREFETCH(pfb, vob, NPB, CQB, t + wgs)
         front_barrier();
