@@ -213,6 +213,51 @@ def test_round5_test_entry_points_validate_their_arguments_without_a_gpu():
     assert L.fh_debug_wino_slots(24) == 0 and L.fh_debug_wino_slots(0) == 0
 
 
+def test_public_header_is_plain_c_and_the_integration_snippet_compiles(tmp_path):
+    """include/facehip.h is the drop-in boundary: it must be consumable from C (cgo / JNI / ctypes-style bindings), not only from C++.
+    The sharded-gallery loop of INTEGRATION.md section 4, written out as C99, compiles with -Wall -Wextra -Werror -pedantic and links
+    against libfacehip.so."""
+    import shutil
+    if not shutil.which("gcc"):
+        pytest.skip("no host C compiler")
+    src = tmp_path / "snippet.c"
+    src.write_text(r"""
+#include <stddef.h>
+#include "facehip.h"
+int sharded_match(fh_det* det, fh_rec* rec, const unsigned char* d_frames, int n, int rows, int cols, int F, fh_face* d_faces, int* d_frame_of,
+                  float* d_emb, const float* shard_rows, long long shard_n, long long first_global_row, int rank, int world, int local_rank,
+                  float* d_scores, int* d_idx, void* stream) {
+    unsigned char id[FH_COMM_ID_BYTES];
+    fh_comm* comm;
+    fh_gallery* g;
+    int nq, rc;
+    if (rank == 0 && fh_comm_unique_id(id) != FH_OK) return -1;
+    /* ... the caller broadcasts id to the other ranks here ... */
+    comm = fh_comm_create(rank, world, id, local_rank);
+    if (!comm) return -2;
+    g = fh_gallery_create(512);
+    if (fh_gallery_upload(g, shard_rows, shard_n, 0, first_global_row) < 0) return -3;
+    nq = fh_pipeline_run_dev(det, rec, d_frames, n, rows, cols, cols * 3, (long long)rows * cols * 3, .5f, .4f, F, d_faces, d_frame_of, d_emb, stream);
+    if (nq < 0) return -4;
+    rc = fh_gallery_topk_sharded_dev(g, comm, d_emb, n * F, 16, d_scores, d_idx, stream);
+    if (rc != fh_comm_world(comm) * n * F) rc = -5;
+    fh_gallery_destroy(g);
+    fh_comm_destroy(comm);
+    return rc;
+}
+int main(void) { return fh_version() == NULL; }
+""")
+    exe = tmp_path / "snippet"
+    lib_dir = os.path.join(ROOT, "facerecognizeonnx_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+           "-L", lib_dir, "-lfacehip", "-Wl,-rpath," + lib_dir]
+    fa.lib()                                                   # (builds libfacehip.so if it is missing)
+    b = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert b.returncode == 0, b.stdout[-3000:]
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout[-2000:]               # fh_version() works without a GPU
+
+
 def _affine_graph(path, H=24, W=20, C=12, Cout=8):
     """conv -> Mul(scalar) -> Add(per-channel) -> Relu -> Dropout -> conv -> Identity -> Sub(scalar) -> Div(per-channel): the
     element-wise constant ops and pass-through nodes exporters leave in graphs (SCRFD's Scale layers, normalisation nodes)."""
