@@ -498,6 +498,22 @@ __device__ __forceinline__ void wino_store_lines(const v16f (&acc)[TN], float* s
 // Round 5 measured two more arrangements of this loop, both bit-identical and both SLOWER, neither kept in the tree: the next chunk's 8 (6)
 // LDS-DMA requests spread over the four k-steps between the MFMAs with the next step's fragments read a half-step ahead (GEMM sum of
 // IResNet-50 at B = 128: 3 189-3 227 us against 3 127-3 160 in the same runs), and several tiles per workgroup (wino_gemm_pers_kernel below).
+#ifdef FACEHIP_WINO_STAMP
+// Diagnostic build (scripts/wino_gemm_stamps.sh): thread 0 of every workgroup of wino_gemm_kernel records the 100 MHz wall clock at entry,
+// when the first chunk has landed, after the K loop and after its last store instruction, into a device buffer the script reads back.
+__device__ unsigned long long g_wino_stamp[8 * 4096];
+extern "C" __attribute__((visibility("default"))) int fh_debug_wino_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_stamp), sizeof(unsigned long long) * (size_t)(n < 8 * 4096 ? n : 8 * 4096)) == hipSuccess ? 0 : -1;
+}
+#define WINO_STAMP(i) if (tid == 0 && blockIdx.x < 4096) g_wino_stamp[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime()
+#else
+#define WINO_STAMP(i)
+#endif
+// Phase stamps (scripts/wino_gemm_stamps.sh, profiles/r05_wino_gemm_stamps.txt; 14x14x256 at B = 128, 968 workgroups of 128x128, two per CU):
+// first chunk 2.2 us, K loop 29.8 us for the two co-resident workgroups of a CU (27.3 at the MFMA peak: the loop itself runs at 0.92),
+// turn-around + stores 2.6 us; the second round starts at 35-44 us with a 4.7 us prologue and a 25.6 us K loop — a workgroup ALONE on its CU
+// does not run twice as fast (one wave per SIMD cannot cover its own chunk latency), which is why a half-tile start stagger of every CU's
+// second workgroup measured +-0 (3 125-3 149 us GEMM sum at 3-9 us of stagger against 3 149-3 158 without).
 // ABL (diagnostic instantiations only, results are garbage): 1 = no loads in the K loop (the first chunk is computed over and over),
 // 2 = no LDS reads (operands stay in registers), 4 = no barriers in the K loop, 8 = no stores, 16 = stores straight from registers
 template <int BN, int OCC, int ABL = 0>
@@ -507,6 +523,7 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __rest
     constexpr int BM = 128, TN = BN / 32, AL = BM / 32, BL = BN / 32;
     __shared__ v4f lds[2][(BM + BN) * 8];
     const int tid = threadIdx.x, lane = tid & 63;
+    WINO_STAMP(0);
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh2 = lane >> 5, fsw = (fr >> 1) & 7;
     // XCD-contiguous tile order (blockIdx % 8 = XCD): the tiles_n workgroups that read the same rows share an L2
@@ -539,6 +556,7 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __rest
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
     load_chunk(0);
     __syncthreads();
+    WINO_STAMP(1);
     v4f xk = v4f{0.f, 0.f, 0.f, 0.f}, wk[TN];
     if constexpr ((ABL & 2) != 0) {
         xk = lds[0][(wid * 32 + fr) * 8 + (fh2 ^ fsw)];
@@ -574,6 +592,7 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __rest
         }
         if constexpr ((ABL & 4) == 0) __syncthreads();
     }
+    WINO_STAMP(2);
     if constexpr ((ABL & 8) != 0) { if (acc[0][0] != 123.456f) return; }
     // Stores.  A lane's accumulators are 4-column pieces of ITS row: stored straight from registers, one instruction writes 32 bytes to
     // each of 32 rows (a quarter of a 128-byte line each, 8 instructions per row).  Instead the wave turns its 32 x BN block around in
@@ -582,6 +601,12 @@ __global__ __launch_bounds__(256, OCC) void wino_gemm_kernel(const float* __rest
     if constexpr ((ABL & 16) == 0) {
         static_assert(4 * 32 * ((TN >= 2 ? 64 : 32) + 4) * sizeof(float) <= sizeof(lds), "store scratch");
         wino_store_lines<TN>(acc, reinterpret_cast<float*>(&lds[0][0]), sizeof(lds), M, N, m0, n0, wid, lane);
+        WINO_STAMP(3);
+#ifdef FACEHIP_WINO_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (diagnostic: when the stores are acknowledged)
+        WINO_STAMP(4);
+        if (tid == 0 && blockIdx.x < 4096) { g_wino_stamp[blockIdx.x * 8 + 5] = (unsigned long long)tile; g_wino_stamp[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((3 << 11) | 20); }
+#endif
         return;
     }
     float* orow = M + (size_t)(m0 + wid * 32 + fr) * N + n0 + 4 * fh2;
